@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — SESPH dam-break throughput on MI355X (BASELINE.json metric: particle-steps/s + ms/step).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NS|C2|C4|...]
+
+A "step" is one update() of the solver (hash → radix sort → cell ranges + reorder → density/pressure →
+forces → integrate) over every particle of the scene, with the particle state already resident in HBM when
+the timed region starts.  N=1 default workload: the north-star size, a 216^3 = 10,077,696-particle SESPH
+dam-break (fp32, Muller kernels) in its tank of boundary particles.  For N>1 (launched by torchrun, one rank
+per GPU) the block is N times longer in x and slab-partitioned (weak scaling), see nereus_amd/slab.py.
+
+Rank 0 prints ONE JSON line: the driver contract plus
+  roofline     dominant kernel, ALGORITHMIC bytes per launch / its mean HIP-event duration in the timed
+               region, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md)
+  cpu_baseline the CPU oracle (a port, OpenMP) on a bounded sample of the same workload, host cores of
+               this box — a reported baseline, not the optimisation target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured-achievable)
+
+# algorithmic bytes per particle per launch of each stage (V=16 B vec4, S=4 B scalar, U=4 B)
+STAGE_BYTES_F32 = {"hash": 16 + 8, "reorder": 8 + 4 * 16 + 2 * 4, "density": 16 + 2 * 4, "forces": 3 * 16 + 2 * 4,
+                   "integrate": 5 * 16}
+
+
+def sesph_bytes_per_particle_step(num_cells, real_bytes=4):
+    """B = 268 + 16 P (fp32) / 516 + 16 P (fp64), P = radix passes of 8 bits over log2(numCells) key bits."""
+    bits = max(1, int(np.ceil(np.log2(max(2, num_cells)))))
+    passes = (bits + 7) // 8
+    base = 268 if real_bytes == 4 else 516
+    return base + 16 * passes, passes
+
+
+def cpu_baseline(seconds_target=15.0):
+    """Time the CPU oracle (restatement of the reference algorithm, OpenMP over particles) on the C1 scene:
+    the same generator and parameters as the GPU workload at 32^3 = 32,768 particles."""
+    from nereus_amd import scene
+    from tests.oracle_lib import SESPH, Oracle
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    p = Oracle.default_params(SESPH)
+    sc = scene.dam_break("C1", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    o = Oracle(p, solver=SESPH, threads=cores)
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    o.step(2)  # warm-up
+    n = len(sc["pos"])
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        o.step(5)
+        steps += 5
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or steps >= 2000:
+            break
+    return {
+        "value": n * steps / dt,
+        "unit": "particle-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "C1: 32^3=32768-particle SESPH dam-break with tank boundaries, %d steps, OpenMP oracle" % steps,
+        "ms_per_step": 1e3 * dt / steps,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="NS", help="scene lattice: NS (216^3), C2 (100^3), C4, C1 ... or nx,ny,nz")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torchrun: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from nereus_amd import capi, scene
+
+    lattice = scene.CONFIGS[args.config] if args.config in scene.CONFIGS else tuple(int(v) for v in args.config.split(","))
+
+    if world > 1:
+        from nereus_amd import slab
+
+        result = slab.bench_main(args, lattice, rank, world, local_rank)
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    # ---------------------------------------------------------------- single GPU
+    from nereus_amd.params import default_params
+
+    p = default_params(0)  # SPH::SPH() constructor defaults (sph/sph.cpp:29-93)
+    t_gen = time.perf_counter()
+    sc = scene.dam_break(lattice, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    t_gen = time.perf_counter() - t_gen
+    n = len(sc["pos"])
+    stream = torch.cuda.current_stream().cuda_stream
+    s = capi.Solver(p, n, solver=capi.SESPH, device=local_rank, stream=stream, reference_order=args.reference_order)
+    s.set_particles(sc["pos"], sc["vel"])
+    s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    P = s.params
+    num_cells = int(P["numCells"][0])
+
+    # warm-up (untimed), with every stage timed once to find the dominant kernel
+    s.set_profiling(True)
+    s.step(args.warmup)
+    s.synchronize()
+    warm = s.stage_ms()
+    dominant = max(warm, key=lambda k: warm[k][0]) if warm else "forces"
+    dom_id = {v: k for k, v in capi.STAGE_NAMES.items()}[dominant]
+    s.set_profiling([dom_id])
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.step(args.steps)
+    s.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timed = s.stage_ms()
+    dom_ms, dom_launches = timed.get(dominant, (0.0, 0))
+
+    # sanity: the state is finite
+    gp, gv = s.download()
+    if not (np.isfinite(gp).all() and np.isfinite(gv).all()):
+        raise SystemExit("non-finite state after the run")
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = n * args.steps / dt
+    bpp, passes = sesph_bytes_per_particle_step(num_cells)
+    dom_bytes = STAGE_BYTES_F32.get(dominant, 0) * n
+    dom_avg_ms = dom_ms / max(1, dom_launches)
+    achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
+    out = {
+        "metric": "particle-steps/sec, SESPH dam-break",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "SESPH dam-break %dx%dx%d = %d particles (+%d tank boundary particles), fp32, Muller kernels, "
+                        "grid %dx%dx%d" % (lattice + (n, len(sc["bi"])) + tuple(int(v) for v in P["gridSize"][0])),
+            "particles": n,
+            "boundary_particles": int(len(sc["bi"])),
+            "num_cells": num_cells,
+            "steps_per_s": args.steps / dt,
+            "kernels": "reference-order" if args.reference_order else "tiled",
+            "parallelism": "1 GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dominant,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel_avg_ms": dom_avg_ms,
+            "kernel_launches": dom_launches,
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "whole_step": {
+                "bytes_per_particle_step": bpp,
+                "radix_passes": passes,
+                "achieved": bpp * value / 1e9,
+                "frac": bpp * value / 1e9 / HBM_PEAK_GBS,
+            },
+        },
+        "stage_ms_warmup_avg": {k: v[0] / max(1, v[1]) for k, v in warm.items()},
+        "scene_build_s": t_gen,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,220 @@
+/*
+ * nereus_hip.h — C ABI of libnereus_hip.so: the MI355X (gfx950) SPH fluid step behind the host
+ * classes Nereus::SPH / Nereus::IISPH.
+ *
+ * This is the boundary a host program binds (C, C++, ctypes, cgo, JNI ...): plain pointers and sizes,
+ * no C++ or torch types.  It REPLACES the reference's CUDA launcher layer, the `extern "C"` block of
+ * sph/sph.cuh:19-230 (defined in sph/sph_cuda.cu).  Two flavours are exported:
+ *
+ *   1. the context API below (nrs_*): device-resident particle state, one call per update();
+ *      this is what nereus_amd/host/ (our Nereus::SPH / Nereus::IISPH) and bench.py use;
+ *   2. the reference's own entry-point names with their sph.cuh signatures (see the second half of
+ *      this header), thin shims over the same kernels, so the reference's unmodified sph.cpp /
+ *      iisph.cpp can link against libnereus_hip.so for A/B runs.
+ *
+ * Conventions: every nrs_* call returns 0 on success, a negative NRS_E_* code otherwise, and
+ * nrs_last_error() gives the message (no exceptions cross the ABI).  The caller owns host buffers,
+ * the library owns device buffers.  A context is bound to one HIP device and one stream; it is not
+ * thread-safe.  Particle arrays are AoS xyzw of SReal exactly as the reference's host arrays
+ * (sph/sph.cpp:341-368): pos4/vel4 = 4*N SReal, scalars = N SReal; SReal = float or double by
+ * nrs_config.precision (the reference's DOUBLE_PRECISION switch, common/common.h:23-43).
+ */
+#ifndef NEREUS_HIP_H
+#define NEREUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SphSimParams (common/sph_kernel.cuh:13-59), SReal=float: 132 bytes, align 4. */
+typedef struct nrs_params_f32 {
+    uint32_t gridSize[3];
+    uint32_t numCells;
+    float worldOrigin[3];
+    float cellSize[3];
+    uint32_t numBodies;
+    uint32_t maxParticlesPerCell;
+    float gasStiffness, viscosity, surfaceTension, restDensity, particleMass, interactionRadius, timestep,
+        particleRadius;
+    float gravity[3];
+    float soundSpeed;
+    float beta;
+    float kpoly, kpoly_grad, kpress_grad, kvisc_grad, kvisc_denum, ksurf1, ksurf2, bpol;
+} nrs_params_f32;
+
+/* SphSimParams, SReal=double: 240 bytes, align 8. */
+typedef struct nrs_params_f64 {
+    uint32_t gridSize[3];
+    uint32_t numCells;
+    double worldOrigin[3];
+    double cellSize[3];
+    uint32_t numBodies;
+    uint32_t maxParticlesPerCell;
+    double gasStiffness, viscosity, surfaceTension, restDensity, particleMass, interactionRadius, timestep,
+        particleRadius;
+    double gravity[3];
+    double soundSpeed;
+    double beta;
+    double kpoly, kpoly_grad, kpress_grad, kvisc_grad, kvisc_denum, ksurf1, ksurf2, bpol;
+} nrs_params_f64;
+
+typedef struct nrs_ctx nrs_ctx;
+
+enum { NRS_SOLVER_SESPH = 0, NRS_SOLVER_IISPH = 1 };     /* Nereus::SPH (sph/sph.h:23) / Nereus::IISPH (iisph.h:8) */
+enum { NRS_KERNELS_MONAGHAN = 0, NRS_KERNELS_MULLER = 1 }; /* KERNEL_SET, common/common.h:14-15 */
+
+/* nrs_config.flags */
+enum {
+    NRS_FLAG_REFERENCE_ORDER = 1u << 0, /* gather kernels walk the 27 cells and sum in exactly the reference's
+                                           order (one thread per slot, per-cell partial sums): slower, used for
+                                           bit-level comparison with the oracle */
+    NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
+                                           offered; P_l is always double-buffered */
+};
+
+/* error codes */
+enum {
+    NRS_OK = 0,
+    NRS_E_INVALID = -1,  /* bad argument */
+    NRS_E_HIP = -2,      /* a HIP runtime call failed */
+    NRS_E_CAPACITY = -3, /* more particles than nrs_config.capacity */
+    NRS_E_STATE = -4,    /* call not valid in the context's current state */
+    NRS_E_NODEVICE = -5, /* no usable HIP device */
+};
+
+typedef struct nrs_config {
+    uint32_t struct_size; /* = sizeof(nrs_config) */
+    int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device */
+    int32_t solver;       /* NRS_SOLVER_* */
+    int32_t precision;    /* 32 or 64: sizeof(SReal)*8 (DOUBLE_PRECISION) */
+    int32_t kernel_set;   /* NRS_KERNELS_* (KERNEL_SET) */
+    int32_t surface_tension; /* USE_SURFACE_TENSION (CMakeLists.txt:28) */
+    uint32_t flags;       /* NRS_FLAG_* */
+    uint32_t reserved;
+    uint64_t capacity;    /* max fluid particles; run-time replacement of MAX_PARTICLE_NUMBER (sph/sph.h:19) */
+    void *stream;         /* hipStream_t to launch on, or NULL to let the context create its own */
+} nrs_config;
+
+/* Pipeline stages, for nrs_step_partial / nrs_stage_ms.  Order is the order of SPH::update()
+ * (sph/sph.cpp:233-284) and IISPH::update() (sph/iisph/iisph.cpp:172-216). */
+enum {
+    NRS_STAGE_HASH = 1,      /* calcHash                     sph_cuda.cu:230 */
+    NRS_STAGE_SORT = 2,      /* sortParticles                sph_cuda.cu:58 */
+    NRS_STAGE_REORDER = 3,   /* reorderDataAndFindCellStart  sph_cuda.cu:295 */
+    NRS_STAGE_DENSITY = 4,   /* computeDensityPressure kernel sph_kernel_impl.cuh:365 */
+    NRS_STAGE_FORCES = 5,    /* computeForces kernel          sph_kernel_impl.cuh:609 */
+    NRS_STAGE_INTEGRATE = 6, /* integrateSystem              sph_cuda.cu:211 */
+    NRS_STAGE_I_DENSITY = 10,      /* computeIisphDensity        sph_kernel_impl.cuh:770 */
+    NRS_STAGE_I_DISPLACEMENT = 11, /* computeDisplacementFactor  :851 */
+    NRS_STAGE_I_ADVECTION = 12,    /* computeAdvectionFactor     :1114 */
+    NRS_STAGE_I_SOLVE = 13,        /* computeSumDijPj + computePressure loop, sph_cuda.cu:736-823 */
+    NRS_STAGE_I_PFORCE = 14,       /* computePressureForce       :1497 */
+    NRS_STAGE_I_INTEGRATE = 15,    /* iisph_integrate            :1625 */
+    NRS_STAGE_COUNT = 16
+};
+
+/* Arrays readable through nrs_get_array / nrs_device_ptr.  "sorted" = in grid-hash order of the
+ * current step, as the reference's m_dSorted* arrays (sph/sph.h:105-111). */
+enum {
+    NRS_ARR_POS = 0,        /* SVec4[N]  current particle positions (what the next update() starts from) */
+    NRS_ARR_VEL = 1,        /* SVec4[N] */
+    NRS_ARR_PRESSURE = 2,   /* SReal[N]  IISPH warm-start pressure (m_pressure, iisph.cpp:216) */
+    NRS_ARR_HASH = 3,       /* uint32[N] sorted cell hashes (m_dGridParticleHash) */
+    NRS_ARR_INDEX = 4,      /* uint32[N] sorted particle indices (m_dGridParticleIndex) */
+    NRS_ARR_CELL_START = 5, /* uint32[numCells], 0xffffffff = empty */
+    NRS_ARR_CELL_END = 6,   /* uint32[numCells], defined only where CELL_START != 0xffffffff */
+    NRS_ARR_SORTED_POS = 7, /* SVec4[N] */
+    NRS_ARR_SORTED_VEL = 8, /* SVec4[N] */
+    NRS_ARR_DENS = 9,       /* SReal[N] */
+    NRS_ARR_PRES = 10,      /* SReal[N] */
+    NRS_ARR_FORCES = 11,    /* SVec4[N] (w=0) */
+    NRS_ARR_B_HASH = 12,    /* boundary: uint32[Nb] */
+    NRS_ARR_B_INDEX = 13,
+    NRS_ARR_B_CELL_START = 14,
+    NRS_ARR_B_CELL_END = 15,
+    NRS_ARR_B_SORTED = 16,  /* SVec4[Nb]: xyz = sorted boundary position, w = its Vbi */
+    NRS_ARR_DENS_ADV = 20,  /* IISPH (sph/iisph/iisph.h:27-41) */
+    NRS_ARR_DENS_CORR = 21,
+    NRS_ARR_P_L = 22,
+    NRS_ARR_AII = 23,
+    NRS_ARR_VEL_ADV = 24,
+    NRS_ARR_FORCES_ADV = 25,
+    NRS_ARR_FORCES_P = 26,
+    NRS_ARR_DII_FLUID = 27,
+    NRS_ARR_DII_BOUNDARY = 28,
+    NRS_ARR_SUM_DIJ = 29,
+};
+
+const char *nrs_last_error(void);
+/* library/ABI version: (major<<16)|minor */
+uint32_t nrs_version(void);
+/* number of HIP devices visible (0 if none / runtime unusable) */
+int nrs_device_count(void);
+
+/* Replaces SPH::SPH()/_initialize() device allocation (sph/sph.cpp:132-188, iisph.cpp:123-159).
+ * `params` points to nrs_params_f32 or nrs_params_f64 according to cfg->precision. */
+int nrs_create(const nrs_config *cfg, const void *params, nrs_ctx **out);
+int nrs_destroy(nrs_ctx *ctx);
+
+/* setParameters (sph/sph.cuh:40, sph_cuda.cu:183-187).  Changing gridSize/numCells re-allocates the
+ * cell tables as SPH::_initializeGrid does (sph.cpp:193-202). */
+int nrs_set_params(nrs_ctx *ctx, const void *params);
+int nrs_get_params(nrs_ctx *ctx, void *params);
+
+/* H2D of particle state: replaces the cudaMemcpy H2D at the top of update() (sph.cpp:233-234,
+ * iisph.cpp:172-174).  Writes particles [first, first+count) and sets N = max(N, first+count).
+ * vel4/pres may be NULL (zeros).  nrs_set_num_particles truncates/extends N within capacity. */
+int nrs_upload_particles(nrs_ctx *ctx, const void *pos4, const void *vel4, const void *pres, uint64_t first,
+                         uint64_t count);
+int nrs_set_num_particles(nrs_ctx *ctx, uint64_t n);
+uint64_t nrs_num_particles(nrs_ctx *ctx);
+
+/* SPH::updateGpuBoundaries (sph/sph.cpp:391-432): upload boundary particles bi4 (SVec4[nb]) and volumes
+ * vbi (SReal[nb]); if update_grid != 0 apply SPH::updateGrid (sph.cpp:313-337: origin = AABBmin-0.1,
+ * gridSize = nextPow2(ceil((extent+0.1)/h))) and re-allocate the cell tables; then hash, sort and
+ * build the boundary cell ranges.  nb = 0 clears the boundaries.  The (possibly new) grid is visible
+ * through nrs_get_params. */
+int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t nb, int update_grid);
+
+/* update() x nsteps with state resident on the device (no per-step PCIe traffic). Asynchronous:
+ * returns after enqueueing; any nrs_download/nrs_get_array/nrs_synchronize waits for completion. */
+int nrs_step(nrs_ctx *ctx, int nsteps);
+/* Test hook: run ONE update() but stop after `stop_stage` (NRS_STAGE_*), leaving the intermediate
+ * arrays readable through nrs_get_array.  After a partial step the particle state is mid-update:
+ * re-upload before stepping again. */
+int nrs_step_partial(nrs_ctx *ctx, int stop_stage);
+int nrs_synchronize(nrs_ctx *ctx);
+
+/* D2H: replaces the cudaMemcpy D2H at the end of update() (sph.cpp:283-284, iisph.cpp:214-216).
+ * Any pointer may be NULL.  Order = grid-hash order of the last step, as in the reference. */
+int nrs_download(nrs_ctx *ctx, void *pos4, void *vel4, void *pres);
+/* Copy one of NRS_ARR_* to host memory (dst_bytes must be >= the array's size; returns it in *out_bytes
+ * when dst == NULL). */
+int nrs_get_array(nrs_ctx *ctx, int which, void *dst, uint64_t dst_bytes, uint64_t *out_bytes);
+/* Device address of one of NRS_ARR_* (valid until the next call that re-allocates or swaps buffers,
+ * i.e. read it after each step).  For zero-copy consumers (renderer VBO upload, halo packing). */
+int nrs_device_ptr(nrs_ctx *ctx, int which, void **dptr, uint64_t *bytes);
+
+/* IISPH: solver iterations of the last step (the `l` of sph_cuda.cu:736). */
+int nrs_last_iterations(nrs_ctx *ctx, uint32_t *iters);
+/* Cap on IISPH solver iterations per step (0 = none, as the reference). */
+int nrs_set_max_iterations(nrs_ctx *ctx, uint32_t max_iters);
+
+/* Per-stage device time, measured with HIP events recorded on the context's stream around the stage's
+ * launches.  stage_mask: bit s set = time NRS_STAGE_s (0 = off, 0xffffffff = every stage).  nrs_stage_ms
+ * returns the time of that stage summed over the steps of the LAST nrs_step call, and how many launches
+ * of the stage that covers. */
+int nrs_set_profiling(nrs_ctx *ctx, uint32_t stage_mask);
+int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches);
+
+/* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
+int nrs_max_density(nrs_ctx *ctx, double *out);
+int nrs_max_velocity(nrs_ctx *ctx, double *out_speed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEREUS_HIP_H */

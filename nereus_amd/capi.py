@@ -1,0 +1,252 @@
+"""ctypes binding of libnereus_hip.so (include/nereus_hip.h).
+
+This is plumbing for tests/bench (Python side); the product host layer is the C++ mirror of the
+reference's classes in nereus_amd/host/.  There is NO CPU fallback: if the shared library is missing
+or no HIP device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import params_dtype
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnereus_hip.so")
+
+SESPH, IISPH = 0, 1
+MONAGHAN, MULLER = 0, 1
+FLAG_REFERENCE_ORDER = 1
+
+# NRS_STAGE_*
+STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
+STAGE_I_DENSITY, STAGE_I_DISPLACEMENT, STAGE_I_ADVECTION, STAGE_I_SOLVE, STAGE_I_PFORCE, STAGE_I_INTEGRATE = (
+    10, 11, 12, 13, 14, 15)
+STAGE_NAMES = {1: "hash", 2: "sort", 3: "reorder", 4: "density", 5: "forces", 6: "integrate", 10: "i_density",
+               11: "i_displacement", 12: "i_advection", 13: "i_solve", 14: "i_pforce", 15: "i_integrate"}
+
+# NRS_ARR_*: name -> (id, kind) with kind in {"v4", "s", "u"}
+ARRAYS = {
+    "pos": (0, "v4"), "vel": (1, "v4"), "pressure": (2, "s"), "hash": (3, "u"), "index": (4, "u"),
+    "cellStart": (5, "u"), "cellEnd": (6, "u"), "sortedPos": (7, "v4"), "sortedVel": (8, "v4"),
+    "dens": (9, "s"), "pres": (10, "s"), "forces": (11, "v4"), "bhash": (12, "u"), "bindex": (13, "u"),
+    "bCellStart": (14, "u"), "bCellEnd": (15, "u"), "bSorted": (16, "v4"),
+    "densAdv": (20, "s"), "densCorr": (21, "s"), "P_l": (22, "s"), "aii": (23, "s"), "velAdv": (24, "v4"),
+    "forcesAdv": (25, "v4"), "forcesP": (26, "v4"), "diiFluid": (27, "v4"), "diiBoundary": (28, "v4"),
+    "sumDij": (29, "v4"),
+}
+
+# every symbol include/nereus_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "nrs_last_error", "nrs_version", "nrs_device_count", "nrs_create", "nrs_destroy", "nrs_set_params",
+    "nrs_get_params", "nrs_upload_particles", "nrs_set_num_particles", "nrs_num_particles", "nrs_set_boundaries",
+    "nrs_step", "nrs_step_partial", "nrs_synchronize", "nrs_download", "nrs_get_array", "nrs_device_ptr",
+    "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
+    "nrs_max_velocity",
+]
+
+
+class NrsConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("solver", C.c_int32), ("precision", C.c_int32),
+        ("kernel_set", C.c_int32), ("surface_tension", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+        ("capacity", C.c_uint64), ("stream", C.c_void_p),
+    ]
+
+
+class NereusError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libnereus_hip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NereusError(
+            "libnereus_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nereus_amd/csrc`; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.nrs_last_error.restype = C.c_char_p
+    lib.nrs_version.restype = C.c_uint32
+    lib.nrs_device_count.restype = i32
+    lib.nrs_create.argtypes = [C.POINTER(NrsConfig), vp, C.POINTER(vp)]
+    lib.nrs_destroy.argtypes = [vp]
+    lib.nrs_set_params.argtypes = [vp, vp]
+    lib.nrs_get_params.argtypes = [vp, vp]
+    lib.nrs_upload_particles.argtypes = [vp, vp, vp, vp, u64, u64]
+    lib.nrs_set_num_particles.argtypes = [vp, u64]
+    lib.nrs_num_particles.argtypes = [vp]
+    lib.nrs_num_particles.restype = u64
+    lib.nrs_set_boundaries.argtypes = [vp, vp, vp, u64, i32]
+    lib.nrs_step.argtypes = [vp, i32]
+    lib.nrs_step_partial.argtypes = [vp, i32]
+    lib.nrs_synchronize.argtypes = [vp]
+    lib.nrs_download.argtypes = [vp, vp, vp, vp]
+    lib.nrs_get_array.argtypes = [vp, i32, vp, u64, C.POINTER(u64)]
+    lib.nrs_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
+    lib.nrs_last_iterations.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.nrs_set_max_iterations.argtypes = [vp, C.c_uint32]
+    lib.nrs_set_profiling.argtypes = [vp, C.c_uint32]
+    lib.nrs_stage_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    lib.nrs_max_density.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.nrs_max_velocity.argtypes = [vp, C.POINTER(C.c_double)]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Solver:
+    """Thin object wrapper over an nrs_ctx (device-resident SESPH / IISPH solver)."""
+
+    def __init__(self, params, capacity, solver=SESPH, double=False, kernel_set=MULLER, surface_tension=True,
+                 reference_order=False, device=-1, stream=None):
+        self.lib = load_library()
+        self.double = bool(double)
+        self.real = np.float64 if double else np.float32
+        self.solver = solver
+        p = np.array(params, dtype=params_dtype(double)).reshape(1).copy()
+        cfg = NrsConfig()
+        cfg.struct_size = C.sizeof(NrsConfig)
+        cfg.device = device
+        cfg.solver = solver
+        cfg.precision = 64 if double else 32
+        cfg.kernel_set = kernel_set
+        cfg.surface_tension = int(bool(surface_tension))
+        cfg.flags = FLAG_REFERENCE_ORDER if reference_order else 0
+        cfg.capacity = int(capacity)
+        cfg.stream = stream
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.lib.nrs_create(C.byref(cfg), _ptr(p), C.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NereusError("libnereus_hip error %d: %s" % (rc, self.lib.nrs_last_error().decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def params(self):
+        p = np.zeros(1, dtype=params_dtype(self.double))
+        self._chk(self.lib.nrs_get_params(self.h, _ptr(p)))
+        return p
+
+    def set_params(self, params):
+        p = np.array(params, dtype=params_dtype(self.double)).reshape(1).copy()
+        self._chk(self.lib.nrs_set_params(self.h, _ptr(p)))
+
+    def set_particles(self, pos4, vel4=None, pres=None, first=0):
+        pos4 = np.ascontiguousarray(pos4, dtype=self.real).reshape(-1, 4)
+        n = pos4.shape[0]
+        vel4 = None if vel4 is None else np.ascontiguousarray(vel4, dtype=self.real)
+        pres = None if pres is None else np.ascontiguousarray(pres, dtype=self.real)
+        if first == 0:
+            self._chk(self.lib.nrs_set_num_particles(self.h, 0))
+        self._chk(self.lib.nrs_upload_particles(self.h, _ptr(pos4), _ptr(vel4), _ptr(pres), first, n))
+
+    def set_boundaries(self, bi4, vbi, update_grid=True):
+        if bi4 is None or len(bi4) == 0:
+            self._chk(self.lib.nrs_set_boundaries(self.h, None, None, 0, 0))
+            return
+        bi4 = np.ascontiguousarray(bi4, dtype=self.real).reshape(-1, 4)
+        vbi = np.ascontiguousarray(vbi, dtype=self.real).reshape(-1)
+        assert vbi.shape[0] == bi4.shape[0]
+        self._chk(self.lib.nrs_set_boundaries(self.h, _ptr(bi4), _ptr(vbi), bi4.shape[0], int(update_grid)))
+
+    @property
+    def n(self):
+        return int(self.lib.nrs_num_particles(self.h))
+
+    def step(self, nsteps=1):
+        self._chk(self.lib.nrs_step(self.h, int(nsteps)))
+
+    def step_partial(self, stage):
+        self._chk(self.lib.nrs_step_partial(self.h, int(stage)))
+
+    def synchronize(self):
+        self._chk(self.lib.nrs_synchronize(self.h))
+
+    def download(self, pressure=False):
+        n = self.n
+        pos = np.empty((n, 4), self.real)
+        vel = np.empty((n, 4), self.real)
+        pres = np.empty(n, self.real) if pressure else None
+        self._chk(self.lib.nrs_download(self.h, _ptr(pos), _ptr(vel), _ptr(pres)))
+        return (pos, vel, pres) if pressure else (pos, vel)
+
+    def get(self, name):
+        aid, kind = ARRAYS[name]
+        nbytes = C.c_uint64(0)
+        self._chk(self.lib.nrs_get_array(self.h, aid, None, 0, C.byref(nbytes)))
+        dt = np.uint32 if kind == "u" else self.real
+        a = np.empty(nbytes.value // np.dtype(dt).itemsize, dtype=dt)
+        if nbytes.value:
+            self._chk(self.lib.nrs_get_array(self.h, aid, _ptr(a), nbytes.value, None))
+        return a.reshape(-1, 4) if kind == "v4" else a
+
+    def device_ptr(self, name):
+        aid, _ = ARRAYS[name]
+        p, b = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.nrs_device_ptr(self.h, aid, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    @property
+    def last_iterations(self):
+        it = C.c_uint32(0)
+        self._chk(self.lib.nrs_last_iterations(self.h, C.byref(it)))
+        return it.value
+
+    def set_max_iterations(self, m):
+        self._chk(self.lib.nrs_set_max_iterations(self.h, int(m)))
+
+    def set_profiling(self, stages=True):
+        """stages: True = all, False = off, or an iterable of stage ids."""
+        if stages is True:
+            mask = 0xFFFFFFFF
+        elif not stages:
+            mask = 0
+        else:
+            mask = 0
+            for s in stages:
+                mask |= 1 << int(s)
+        self._chk(self.lib.nrs_set_profiling(self.h, mask))
+
+    def stage_ms(self):
+        """{stage name: (ms summed over the last nrs_step call, launches)}"""
+        out = {}
+        for sid, name in STAGE_NAMES.items():
+            ms, cnt = C.c_float(0), C.c_uint32(0)
+            self._chk(self.lib.nrs_stage_ms(self.h, sid, C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[name] = (ms.value, cnt.value)
+        return out
+
+    def max_density(self):
+        v = C.c_double()
+        self._chk(self.lib.nrs_max_density(self.h, C.byref(v)))
+        return v.value
+
+    def max_velocity(self):
+        v = C.c_double()
+        self._chk(self.lib.nrs_max_velocity(self.h, C.byref(v)))
+        return v.value

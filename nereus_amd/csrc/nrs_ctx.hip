@@ -1,0 +1,769 @@
+// nrs_ctx.hip — context object and C ABI of libnereus_hip.so (see include/nereus_hip.h).
+//
+// The context owns the device-resident particle state and sequences one update() exactly as the
+// reference's host classes do (SPH::update sph/sph.cpp:215-285, IISPH::update sph/iisph/iisph.cpp:170-217,
+// predictAdvection/pressureSolve sph/sph_cuda.cu:513-899) — minus the per-step PCIe copies: the
+// "unsorted" arrays of step t+1 are the integrated sorted arrays of step t (buffer swap), which is what
+// the reference obtains by copying sorted→host→device.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/nereus_hip.h"
+#include "nrs_kernels_ref.h"
+#include "nrs_kernels_tiled.h"
+
+namespace nrs {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(NRS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                       std::to_string(__LINE__) + ")");                                  \
+    } while (0)
+#define NRSCHK(expr)              \
+    do {                          \
+        int r_ = (expr);          \
+        if (r_ != NRS_OK) return r_; \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n)
+    {
+        if (n <= bytes && p) return NRS_OK;
+        release();
+        if (n == 0) return NRS_OK;
+        HIPCHK(hipMalloc(&p, n));
+        bytes = n;
+        return NRS_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+static inline uint32_t nblocks(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+
+static uint32_t next_pow2(uint32_t v) // sph/sph.cpp:300-311
+{
+    v--;
+    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    v++;
+    return v;
+}
+
+struct CtxBase {
+    virtual ~CtxBase() {}
+    virtual int init(const nrs_config &cfg, const void *params) = 0;
+    virtual int set_params(const void *params) = 0;
+    virtual int get_params(void *params) = 0;
+    virtual int upload(const void *pos4, const void *vel4, const void *pres, uint64_t first, uint64_t count) = 0;
+    virtual int set_n(uint64_t n) = 0;
+    virtual uint64_t get_n() = 0;
+    virtual int set_boundaries(const void *bi4, const void *vbi, uint64_t nb, int update_grid) = 0;
+    virtual int step(int nsteps, int stop) = 0;
+    virtual int sync() = 0;
+    virtual int download(void *pos4, void *vel4, void *pres) = 0;
+    virtual int array(int which, void **dptr, uint64_t *bytes) = 0;
+    virtual int stage_ms(int stage, float *ms, uint32_t *launches) = 0;
+    virtual int reduce_max(int which, double *out) = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int device = 0;
+    uint32_t lastIters = 0, maxIters = 0;
+    uint32_t profMask = 0;
+};
+
+template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
+    typedef typename Vec4T<R>::type T4;
+    Params<R> P;
+    nrs_config cfg;
+    uint64_t cap = 0, n = 0, nb = 0;
+    bool midStep = false; // a partial step left the state mid-update
+    // particle state: A = current ("unsorted" input of the next step), B = sorted work arrays
+    DevBuf posA, posB, velA, velB, presA, presB, dens, forces;
+    DevBuf hashA, hashB, indexA, indexB, inv, sortTmp;
+    uint32_t *hashCur = nullptr, *indexCur = nullptr; // sorted keys/values after the sort stage
+    DevBuf cellStart, cellEnd, bCellStart, bCellEnd;
+    uint32_t cellsAllocated = 0;
+    // boundaries
+    DevBuf bSorted, bHash, bIndex, bHashAlt, bIndexAlt;
+    uint32_t *bHashCur = nullptr, *bIndexCur = nullptr;
+    // IISPH
+    DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij;
+    DevBuf redPartial, redOut;
+    // profiling
+    struct Ev { int stage; hipEvent_t a, b; };
+    std::vector<Ev> evPool;
+    size_t evUsed = 0;
+    float stageMs[NRS_STAGE_COUNT] = {0};
+    uint32_t stageLaunches[NRS_STAGE_COUNT] = {0};
+    bool evOpen = false;
+
+    // the tiled kernels assume the power-of-two grids the reference's hash assumes (sph_kernel_impl.cuh:120)
+    bool refOrder() const
+    {
+        return (cfg.flags & NRS_FLAG_REFERENCE_ORDER) != 0 || !is_pow2(P.gridSize[0]) || !is_pow2(P.gridSize[1]) ||
+               !is_pow2(P.gridSize[2]);
+    }
+    bool iisph() const { return cfg.solver == NRS_SOLVER_IISPH; }
+
+    ~Ctx() override
+    {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &e : evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
+                         &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
+                         &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
+                         &diiF, &diiB, &sumDij, &redPartial, &redOut};
+        for (DevBuf *b : all) b->release();
+        if (ownStream && stream) (void)hipStreamDestroy(stream);
+    }
+
+    int alloc_cells()
+    {
+        const uint64_t C = P.numCells;
+        if (C == 0 || C > (1ull << 31)) return fail(NRS_E_INVALID, "numCells out of range");
+        NRSCHK(cellStart.alloc(C * 4));
+        NRSCHK(cellEnd.alloc(C * 4));
+        if (nb) {
+            NRSCHK(bCellStart.alloc(C * 4));
+            NRSCHK(bCellEnd.alloc(C * 4));
+        }
+        if (cellsAllocated != C) {
+            HIPCHK(hipMemsetAsync(cellEnd.p, 0, C * 4, stream));
+            if (nb) HIPCHK(hipMemsetAsync(bCellEnd.p, 0, C * 4, stream));
+            cellsAllocated = (uint32_t)C;
+        }
+        return NRS_OK;
+    }
+
+    int init(const nrs_config &c, const void *params) override
+    {
+        cfg = c;
+        cap = c.capacity;
+        if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "capacity must be in 1..2^30-1");
+        std::memcpy(&P, params, sizeof(P));
+        const size_t v = sizeof(T4) * cap, s = sizeof(R) * cap, u = 4 * cap;
+        NRSCHK(posA.alloc(v)); NRSCHK(posB.alloc(v)); NRSCHK(velA.alloc(v)); NRSCHK(velB.alloc(v));
+        NRSCHK(presA.alloc(s)); NRSCHK(presB.alloc(s)); NRSCHK(dens.alloc(s)); NRSCHK(forces.alloc(v));
+        NRSCHK(hashA.alloc(u)); NRSCHK(hashB.alloc(u)); NRSCHK(indexA.alloc(u)); NRSCHK(indexB.alloc(u));
+        HIPCHK(hipMemsetAsync(presA.p, 0, s, stream));
+        HIPCHK(hipMemsetAsync(presB.p, 0, s, stream));
+        HIPCHK(hipMemsetAsync(dens.p, 0, s, stream));
+        HIPCHK(hipMemsetAsync(forces.p, 0, v, stream));
+        if (iisph()) {
+            NRSCHK(inv.alloc(u));
+            NRSCHK(densAdv.alloc(s)); NRSCHK(densCorr.alloc(s)); NRSCHK(P_l.alloc(s)); NRSCHK(P_l2.alloc(s));
+            NRSCHK(aii.alloc(s));
+            NRSCHK(velAdv.alloc(v)); NRSCHK(forcesAdv.alloc(v)); NRSCHK(forcesP.alloc(v));
+            NRSCHK(diiF.alloc(v)); NRSCHK(diiB.alloc(v)); NRSCHK(sumDij.alloc(v));
+            DevBuf *z[] = {&densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP, &diiF, &diiB, &sumDij};
+            for (DevBuf *b : z) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, stream));
+        }
+        NRSCHK(redPartial.alloc(sizeof(double) * 1024));
+        NRSCHK(redOut.alloc(sizeof(double)));
+        // radix sort workspace for the largest problem
+        size_t tmp = 0;
+        rocprim::double_buffer<uint32_t> k(hashA.as<uint32_t>(), hashB.as<uint32_t>());
+        rocprim::double_buffer<uint32_t> vv(indexA.as<uint32_t>(), indexB.as<uint32_t>());
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, k, vv, (size_t)cap, 0u, 32u, stream));
+        NRSCHK(sortTmp.alloc(tmp));
+        NRSCHK(alloc_cells());
+        return NRS_OK;
+    }
+
+    int set_params(const void *params) override
+    {
+        Params<R> q;
+        std::memcpy(&q, params, sizeof(q));
+        const bool regrid = q.numCells != P.numCells;
+        P = q;
+        if (regrid) {
+            NRSCHK(alloc_cells());
+            if (nb) NRSCHK(rebuild_boundary_tables());
+        }
+        return NRS_OK;
+    }
+    int get_params(void *params) override
+    {
+        std::memcpy(params, &P, sizeof(P));
+        return NRS_OK;
+    }
+
+    int upload(const void *pos4, const void *vel4, const void *pres, uint64_t first, uint64_t count) override
+    {
+        if (first + count > cap) return fail(NRS_E_CAPACITY, "upload exceeds capacity");
+        if (count) {
+            if (!pos4) return fail(NRS_E_INVALID, "pos4 is NULL");
+            HIPCHK(hipMemcpyAsync(posA.as<T4>() + first, pos4, sizeof(T4) * count, hipMemcpyHostToDevice, stream));
+            if (vel4) HIPCHK(hipMemcpyAsync(velA.as<T4>() + first, vel4, sizeof(T4) * count, hipMemcpyHostToDevice, stream));
+            else HIPCHK(hipMemsetAsync(velA.as<T4>() + first, 0, sizeof(T4) * count, stream));
+            if (pres) HIPCHK(hipMemcpyAsync(presA.as<R>() + first, pres, sizeof(R) * count, hipMemcpyHostToDevice, stream));
+            else HIPCHK(hipMemsetAsync(presA.as<R>() + first, 0, sizeof(R) * count, stream));
+            HIPCHK(hipStreamSynchronize(stream)); // the caller may reuse its host buffers on return
+        }
+        if (first + count > n) n = first + count;
+        midStep = false;
+        return NRS_OK;
+    }
+    int set_n(uint64_t nn) override
+    {
+        if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
+        n = nn;
+        return NRS_OK;
+    }
+    uint64_t get_n() override { return n; }
+
+    // ---- boundaries: SPH::updateGpuBoundaries / updateGrid (sph/sph.cpp:313-337, 391-432) ----------
+    std::vector<T4> hostBi;
+    std::vector<R> hostVbi;
+
+    uint32_t sort_end_bit() const
+    {
+        uint32_t bits = 1;
+        while (bits < 32 && (1ull << bits) < (uint64_t)P.numCells) ++bits;
+        return bits;
+    }
+
+    int rebuild_boundary_tables()
+    {
+        if (!nb) return NRS_OK;
+        NRSCHK(alloc_cells());
+        DevBuf dBi, dVbi;
+        NRSCHK(dBi.alloc(sizeof(T4) * nb));
+        NRSCHK(dVbi.alloc(sizeof(R) * nb));
+        HIPCHK(hipMemcpyAsync(dBi.p, hostBi.data(), sizeof(T4) * nb, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(dVbi.p, hostVbi.data(), sizeof(R) * nb, hipMemcpyHostToDevice, stream));
+        NRSCHK(bHash.alloc(4 * nb)); NRSCHK(bIndex.alloc(4 * nb)); NRSCHK(bHashAlt.alloc(4 * nb)); NRSCHK(bIndexAlt.alloc(4 * nb));
+        NRSCHK(bSorted.alloc(sizeof(T4) * nb));
+        hipLaunchKernelGGL((k_hash<R>), dim3(nblocks(nb)), dim3(BLOCK), 0, stream, P, dBi.as<T4>(), bHash.as<uint32_t>(),
+                           bIndex.as<uint32_t>(), (uint32_t)nb);
+        size_t tmp = 0;
+        rocprim::double_buffer<uint32_t> k(bHash.as<uint32_t>(), bHashAlt.as<uint32_t>());
+        rocprim::double_buffer<uint32_t> v(bIndex.as<uint32_t>(), bIndexAlt.as<uint32_t>());
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, k, v, (size_t)nb, 0u, sort_end_bit(), stream));
+        DevBuf t;
+        NRSCHK(t.alloc(tmp));
+        HIPCHK(rocprim::radix_sort_pairs(t.p, tmp, k, v, (size_t)nb, 0u, sort_end_bit(), stream));
+        bHashCur = k.current();
+        bIndexCur = v.current();
+        HIPCHK(hipMemsetAsync(bCellStart.p, 0xff, (size_t)P.numCells * 4, stream));
+        hipLaunchKernelGGL((k_reorder_boundary<R>), dim3(nblocks(nb)), dim3(BLOCK), 0, stream, bHashCur, bIndexCur,
+                           dBi.as<T4>(), dVbi.as<R>(), bSorted.as<T4>(), bCellStart.as<uint32_t>(),
+                           bCellEnd.as<uint32_t>(), (uint32_t)nb);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        t.release(); dBi.release(); dVbi.release();
+        return NRS_OK;
+    }
+
+    int set_boundaries(const void *bi4, const void *vbi, uint64_t nbNew, int update_grid) override
+    {
+        if (nbNew > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "too many boundary particles (max 2^30-1)");
+        if (nbNew && (!bi4 || !vbi)) return fail(NRS_E_INVALID, "bi4/vbi is NULL");
+        nb = nbNew;
+        hostBi.assign((const T4 *)bi4, (const T4 *)bi4 + nb);
+        hostVbi.assign((const R *)vbi, (const R *)vbi + nb);
+        if (!nb) return NRS_OK;
+        if (update_grid) {
+            // BBMin/BBMax (sph_cuda.cu:461-505) + SPH::updateGrid (sph.cpp:313-337)
+            R mn[3] = {hostBi[0].x, hostBi[0].y, hostBi[0].z}, mx[3] = {hostBi[0].x, hostBi[0].y, hostBi[0].z};
+            for (uint64_t i = 1; i < nb; ++i) {
+                const R c[3] = {hostBi[i].x, hostBi[i].y, hostBi[i].z};
+                for (int a = 0; a < 3; ++a) {
+                    if (c[a] < mn[a]) mn[a] = c[a];
+                    if (mx[a] < c[a]) mx[a] = c[a];
+                }
+            }
+            uint32_t g[3];
+            for (int a = 0; a < 3; ++a) {
+                P.worldOrigin[a] = (R)(mn[a] - 0.1);
+                const uint32_t sz = (uint32_t)std::ceil((mx[a] - mn[a] + 0.1) / P.interactionRadius);
+                g[a] = next_pow2(sz);
+            }
+            const uint64_t C = (uint64_t)g[0] * g[1] * g[2];
+            if (C > (1ull << 31)) return fail(NRS_E_INVALID, "grid from boundary AABB exceeds 2^31 cells");
+            P.gridSize[0] = g[0]; P.gridSize[1] = g[1]; P.gridSize[2] = g[2];
+            P.numCells = (uint32_t)C;
+        }
+        return rebuild_boundary_tables();
+    }
+
+    // ---- profiling helpers ------------------------------------------------------------------------
+    int ev_begin(int stage)
+    {
+        evOpen = (profMask >> stage) & 1u;
+        if (!evOpen) return NRS_OK;
+        if (evUsed == evPool.size()) {
+            Ev e; e.stage = stage;
+            HIPCHK(hipEventCreate(&e.a));
+            HIPCHK(hipEventCreate(&e.b));
+            evPool.push_back(e);
+        }
+        evPool[evUsed].stage = stage;
+        HIPCHK(hipEventRecord(evPool[evUsed].a, stream));
+        return NRS_OK;
+    }
+    int ev_end()
+    {
+        if (!evOpen) return NRS_OK;
+        evOpen = false;
+        HIPCHK(hipEventRecord(evPool[evUsed].b, stream));
+        ++evUsed;
+        return NRS_OK;
+    }
+    int ev_collect()
+    {
+        if (!profMask || !evUsed) return NRS_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < evUsed; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, evPool[i].a, evPool[i].b));
+            stageMs[evPool[i].stage] += ms;
+            stageLaunches[evPool[i].stage] += 1;
+        }
+        evUsed = 0;
+        return NRS_OK;
+    }
+    int stage_ms(int stage, float *ms, uint32_t *launches) override
+    {
+        if (stage < 0 || stage >= NRS_STAGE_COUNT) return fail(NRS_E_INVALID, "bad stage");
+        *ms = stageMs[stage];
+        if (launches) *launches = stageLaunches[stage];
+        return NRS_OK;
+    }
+
+    GridView<R> grid_view() const
+    {
+        GridView<R> G;
+        G.cellStart = cellStart.as<uint32_t>(); G.cellEnd = cellEnd.as<uint32_t>();
+        G.bCellStart = bCellStart.as<uint32_t>(); G.bCellEnd = bCellEnd.as<uint32_t>();
+        G.sB = bSorted.as<T4>();
+        return G;
+    }
+    IisphArrays<R> iisph_view() const
+    {
+        IisphArrays<R> I;
+        I.densAdv = densAdv.as<R>(); I.densCorr = densCorr.as<R>(); I.P_l = P_l.as<R>(); I.P_l_next = P_l2.as<R>();
+        I.aii = aii.as<R>();
+        I.velAdv = velAdv.as<T4>(); I.forcesAdv = forcesAdv.as<T4>(); I.forcesP = forcesP.as<T4>();
+        I.diiF = diiF.as<T4>(); I.diiB = diiB.as<T4>(); I.sumDij = sumDij.as<T4>();
+        I.inv = inv.as<uint32_t>();
+        return I;
+    }
+
+    // hash → sort → cell ranges + reorder: common prefix of both solvers
+    int stage_prefix(int stop)
+    {
+        const uint32_t N = (uint32_t)n;
+        const dim3 g(nblocks(N)), b(BLOCK);
+        NRSCHK(ev_begin(NRS_STAGE_HASH));
+        hipLaunchKernelGGL((k_hash<R>), g, b, 0, stream, P, posA.as<T4>(), hashA.as<uint32_t>(), indexA.as<uint32_t>(), N);
+        NRSCHK(ev_end());
+        hashCur = hashA.as<uint32_t>(); indexCur = indexA.as<uint32_t>();
+        if (stop == NRS_STAGE_HASH) return NRS_OK;
+
+        NRSCHK(ev_begin(NRS_STAGE_SORT));
+        rocprim::double_buffer<uint32_t> k(hashA.as<uint32_t>(), hashB.as<uint32_t>());
+        rocprim::double_buffer<uint32_t> v(indexA.as<uint32_t>(), indexB.as<uint32_t>());
+        size_t tmp = sortTmp.bytes;
+        HIPCHK(rocprim::radix_sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, 0u, sort_end_bit(), stream));
+        hashCur = k.current(); indexCur = v.current();
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_SORT) return NRS_OK;
+
+        NRSCHK(ev_begin(NRS_STAGE_REORDER));
+        HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
+        hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
+                           iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
+                           cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
+        NRSCHK(ev_end());
+        return NRS_OK;
+    }
+
+    template <bool HAS_B> int sesph_tail(int stop)
+    {
+        const uint32_t N = (uint32_t)n;
+        const dim3 g(nblocks(N)), b(BLOCK);
+        const GridView<R> G = grid_view();
+        NRSCHK(ev_begin(NRS_STAGE_DENSITY));
+        if (refOrder())
+            hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        else
+            launch_density_tiled<R, KSET, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_DENSITY) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_FORCES));
+        if (refOrder())
+            hipLaunchKernelGGL((k_forces_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), forces.as<T4>(), N);
+        else
+            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), velB.as<T4>(), dens.as<R>(),
+                                                      presB.as<R>(), forces.as<T4>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_FORCES) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_INTEGRATE));
+        hipLaunchKernelGGL((k_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), forces.as<T4>(), N);
+        NRSCHK(ev_end());
+        return NRS_OK;
+    }
+
+    int reduce_sum(const R *a, uint32_t N, double *out)
+    {
+        const uint32_t nbk = std::min<uint32_t>(1024u, nblocks(N));
+        hipLaunchKernelGGL((k_sum_partial<R>), dim3(nbk), dim3(BLOCK), 0, stream, a, redPartial.as<double>(), N);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BLOCK), 0, stream, redPartial.as<double>(), redOut.as<double>(), nbk);
+        HIPCHK(hipMemcpyAsync(out, redOut.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return NRS_OK;
+    }
+    int reduce_max(int which, double *out) override
+    {
+        if (!n) { *out = 0; return NRS_OK; }
+        const uint32_t N = (uint32_t)n;
+        const uint32_t nbk = std::min<uint32_t>(1024u, nblocks(N));
+        if (which == 0)
+            hipLaunchKernelGGL((k_max_partial<R, false>), dim3(nbk), dim3(BLOCK), 0, stream, (const void *)dens.p, redPartial.as<double>(), N);
+        else
+            hipLaunchKernelGGL((k_max_partial<R, true>), dim3(nbk), dim3(BLOCK), 0, stream, (const void *)velA.p, redPartial.as<double>(), N);
+        std::vector<double> h(nbk);
+        HIPCHK(hipMemcpyAsync(h.data(), redPartial.p, sizeof(double) * nbk, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        double m = h[0];
+        for (uint32_t i = 1; i < nbk; ++i) m = std::max(m, h[i]);
+        *out = m;
+        return NRS_OK;
+    }
+
+    template <bool HAS_B> int iisph_tail(int stop)
+    {
+        const uint32_t N = (uint32_t)n;
+        const dim3 g(nblocks(N)), b(BLOCK);
+        const GridView<R> G = grid_view();
+        IisphArrays<R> I = iisph_view();
+        // predictAdvection (sph_cuda.cu:513-697)
+        NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
+        hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), (R *)nullptr, N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_DENSITY) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_I_DISPLACEMENT));
+        hipLaunchKernelGGL((k_displacement_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
+                           dens.as<R>(), presB.as<R>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_DISPLACEMENT) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_I_ADVECTION));
+        hipLaunchKernelGGL((k_advection_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
+                           dens.as<R>(), presB.as<R>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_ADVECTION) return NRS_OK;
+        // pressureSolve (sph_cuda.cu:702-899): while ((rho_avg - 1000) > 1 || l < 2)
+        NRSCHK(ev_begin(NRS_STAGE_I_SOLVE));
+        uint32_t l = 0;
+        R rho_avg = 0.f;
+        const R rd = 1000.f;
+        const R max_rho_err = 1.f;
+        while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
+            hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
+            hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
+                               presB.as<R>(), N);
+            std::swap(I.P_l, I.P_l_next);
+            std::swap(P_l.p, P_l2.p);
+            double acc = 0.0;
+            NRSCHK(reduce_sum(densCorr.as<R>(), N, &acc));
+            rho_avg = (R)acc;
+            rho_avg /= N;
+            l++;
+            if (maxIters && l >= maxIters) break;
+        }
+        lastIters = l;
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_SOLVE) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
+        hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_PFORCE) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_I_INTEGRATE));
+        hipLaunchKernelGGL((k_iisph_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), velAdv.as<T4>(), forcesP.as<T4>(), N);
+        NRSCHK(ev_end());
+        return NRS_OK;
+    }
+
+    int step(int nsteps, int stop) override
+    {
+        if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
+        if (n == 0) return NRS_OK;
+        if (profMask) { std::memset(stageMs, 0, sizeof(stageMs)); std::memset(stageLaunches, 0, sizeof(stageLaunches)); }
+        for (int s = 0; s < nsteps; ++s) {
+            NRSCHK(stage_prefix(stop));
+            if (stop && stop <= NRS_STAGE_REORDER) { midStep = true; break; }
+            if (iisph()) { if (nb) NRSCHK(iisph_tail<true>(stop)); else NRSCHK(iisph_tail<false>(stop)); }
+            else { if (nb) NRSCHK(sesph_tail<true>(stop)); else NRSCHK(sesph_tail<false>(stop)); }
+            HIPCHK(hipGetLastError());
+            if (stop) { midStep = true; break; }
+            // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
+            std::swap(posA.p, posB.p);
+            std::swap(velA.p, velB.p);
+            if (iisph()) std::swap(presA.p, presB.p);
+        }
+        HIPCHK(hipGetLastError());
+        NRSCHK(ev_collect());
+        return NRS_OK;
+    }
+    int sync() override
+    {
+        HIPCHK(hipStreamSynchronize(stream));
+        return NRS_OK;
+    }
+    int download(void *pos4, void *vel4, void *pres) override
+    {
+        if (pos4) HIPCHK(hipMemcpyAsync(pos4, posA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
+        if (vel4) HIPCHK(hipMemcpyAsync(vel4, velA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
+        if (pres) HIPCHK(hipMemcpyAsync(pres, presA.p, sizeof(R) * n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return NRS_OK;
+    }
+    int array(int which, void **dptr, uint64_t *bytes) override
+    {
+        const uint64_t v = sizeof(T4) * n, s = sizeof(R) * n, u = 4 * n, c = 4ull * P.numCells;
+        void *p = nullptr;
+        uint64_t sz = 0;
+        // after a completed step the sorted arrays ARE the current arrays (buffers were swapped)
+        const bool sortedIsCurrent = !midStep;
+        switch (which) {
+        case NRS_ARR_POS: p = posA.p; sz = v; break;
+        case NRS_ARR_VEL: p = velA.p; sz = v; break;
+        case NRS_ARR_PRESSURE: p = presA.p; sz = s; break;
+        case NRS_ARR_HASH: p = hashCur; sz = u; break;
+        case NRS_ARR_INDEX: p = indexCur; sz = u; break;
+        case NRS_ARR_CELL_START: p = cellStart.p; sz = c; break;
+        case NRS_ARR_CELL_END: p = cellEnd.p; sz = c; break;
+        case NRS_ARR_SORTED_POS: p = sortedIsCurrent ? posA.p : posB.p; sz = v; break;
+        case NRS_ARR_SORTED_VEL: p = sortedIsCurrent ? velA.p : velB.p; sz = v; break;
+        case NRS_ARR_DENS: p = dens.p; sz = s; break;
+        case NRS_ARR_PRES: p = (iisph() && sortedIsCurrent) ? presA.p : presB.p; sz = s; break;
+        case NRS_ARR_FORCES: p = forces.p; sz = v; break;
+        case NRS_ARR_B_HASH: p = bHashCur; sz = 4 * nb; break;
+        case NRS_ARR_B_INDEX: p = bIndexCur; sz = 4 * nb; break;
+        case NRS_ARR_B_CELL_START: p = nb ? bCellStart.p : nullptr; sz = nb ? c : 0; break;
+        case NRS_ARR_B_CELL_END: p = nb ? bCellEnd.p : nullptr; sz = nb ? c : 0; break;
+        case NRS_ARR_B_SORTED: p = bSorted.p; sz = sizeof(T4) * nb; break;
+        case NRS_ARR_DENS_ADV: p = densAdv.p; sz = s; break;
+        case NRS_ARR_DENS_CORR: p = densCorr.p; sz = s; break;
+        case NRS_ARR_P_L: p = P_l.p; sz = s; break;
+        case NRS_ARR_AII: p = aii.p; sz = s; break;
+        case NRS_ARR_VEL_ADV: p = velAdv.p; sz = v; break;
+        case NRS_ARR_FORCES_ADV: p = forcesAdv.p; sz = v; break;
+        case NRS_ARR_FORCES_P: p = forcesP.p; sz = v; break;
+        case NRS_ARR_DII_FLUID: p = diiF.p; sz = v; break;
+        case NRS_ARR_DII_BOUNDARY: p = diiB.p; sz = v; break;
+        case NRS_ARR_SUM_DIJ: p = sumDij.p; sz = v; break;
+        default: return fail(NRS_E_INVALID, "unknown array id");
+        }
+        if (which >= NRS_ARR_DENS_ADV && !iisph()) return fail(NRS_E_STATE, "IISPH array requested from a SESPH context");
+        *dptr = p;
+        *bytes = p ? sz : 0;
+        return NRS_OK;
+    }
+};
+
+template <typename R, int KSET> static CtxBase *make_ctx2(bool surf)
+{
+    if (surf) return new Ctx<R, KSET, true>();
+    return new Ctx<R, KSET, false>();
+}
+static CtxBase *make_ctx(const nrs_config &c)
+{
+    if (c.precision == 32) return c.kernel_set == NRS_KERNELS_MULLER ? make_ctx2<float, KS_MULLER>(c.surface_tension != 0) : make_ctx2<float, KS_MONAGHAN>(c.surface_tension != 0);
+    return c.kernel_set == NRS_KERNELS_MULLER ? make_ctx2<double, KS_MULLER>(c.surface_tension != 0) : make_ctx2<double, KS_MONAGHAN>(c.surface_tension != 0);
+}
+
+} // namespace nrs
+
+using namespace nrs;
+
+struct nrs_ctx { CtxBase *impl; };
+
+#define CTX_GUARD(ctx)                                                   \
+    if (!(ctx) || !(ctx)->impl) return fail(NRS_E_INVALID, "NULL context"); \
+    if (hipSetDevice((ctx)->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed")
+
+extern "C" {
+
+const char *nrs_last_error(void) { return g_err.c_str(); }
+uint32_t nrs_version(void) { return (0u << 16) | 1u; }
+int nrs_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nrs_create(const nrs_config *cfg, const void *params, nrs_ctx **out)
+{
+    if (!cfg || !params || !out) return fail(NRS_E_INVALID, "NULL argument");
+    if (cfg->struct_size != sizeof(nrs_config)) return fail(NRS_E_INVALID, "nrs_config.struct_size mismatch");
+    if (cfg->precision != 32 && cfg->precision != 64) return fail(NRS_E_INVALID, "precision must be 32 or 64");
+    if (cfg->kernel_set != NRS_KERNELS_MULLER && cfg->kernel_set != NRS_KERNELS_MONAGHAN) return fail(NRS_E_INVALID, "bad kernel_set");
+    if (cfg->solver != NRS_SOLVER_SESPH && cfg->solver != NRS_SOLVER_IISPH) return fail(NRS_E_INVALID, "bad solver");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NRS_E_NODEVICE, "no HIP device available: libnereus_hip has no CPU fallback");
+    int dev = cfg->device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(NRS_E_INVALID, "device ordinal out of range");
+    HIPCHK(hipSetDevice(dev));
+    CtxBase *c = make_ctx(*cfg);
+    c->device = dev;
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        hipStream_t s;
+        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(NRS_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+        c->stream = s;
+        c->ownStream = true;
+    }
+    int r = c->init(*cfg, params);
+    if (r != NRS_OK) { delete c; return r; }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { delete c; return fail(NRS_E_HIP, std::string("init sync: ") + hipGetErrorString(e)); }
+    *out = new nrs_ctx{c};
+    return NRS_OK;
+}
+int nrs_destroy(nrs_ctx *ctx)
+{
+    if (!ctx) return NRS_OK;
+    delete ctx->impl;
+    delete ctx;
+    return NRS_OK;
+}
+int nrs_set_params(nrs_ctx *ctx, const void *params)
+{
+    CTX_GUARD(ctx);
+    if (!params) return fail(NRS_E_INVALID, "NULL params");
+    return ctx->impl->set_params(params);
+}
+int nrs_get_params(nrs_ctx *ctx, void *params)
+{
+    CTX_GUARD(ctx);
+    if (!params) return fail(NRS_E_INVALID, "NULL params");
+    return ctx->impl->get_params(params);
+}
+int nrs_upload_particles(nrs_ctx *ctx, const void *pos4, const void *vel4, const void *pres, uint64_t first, uint64_t count)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->upload(pos4, vel4, pres, first, count);
+}
+int nrs_set_num_particles(nrs_ctx *ctx, uint64_t n)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->set_n(n);
+}
+uint64_t nrs_num_particles(nrs_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->get_n() : 0; }
+int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t nb, int update_grid)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->set_boundaries(bi4, vbi, nb, update_grid);
+}
+int nrs_step(nrs_ctx *ctx, int nsteps)
+{
+    CTX_GUARD(ctx);
+    if (nsteps < 0) return fail(NRS_E_INVALID, "nsteps < 0");
+    return ctx->impl->step(nsteps, 0);
+}
+int nrs_step_partial(nrs_ctx *ctx, int stop_stage)
+{
+    CTX_GUARD(ctx);
+    if (stop_stage <= 0 || stop_stage >= NRS_STAGE_COUNT) return fail(NRS_E_INVALID, "bad stop_stage");
+    return ctx->impl->step(1, stop_stage);
+}
+int nrs_synchronize(nrs_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->sync();
+}
+int nrs_download(nrs_ctx *ctx, void *pos4, void *vel4, void *pres)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->download(pos4, vel4, pres);
+}
+int nrs_get_array(nrs_ctx *ctx, int which, void *dst, uint64_t dst_bytes, uint64_t *out_bytes)
+{
+    CTX_GUARD(ctx);
+    void *p = nullptr;
+    uint64_t sz = 0;
+    NRSCHK(ctx->impl->array(which, &p, &sz));
+    if (out_bytes) *out_bytes = sz;
+    if (!dst) return NRS_OK;
+    if (dst_bytes < sz) return fail(NRS_E_INVALID, "destination too small");
+    if (sz) {
+        HIPCHK(hipMemcpyAsync(dst, p, sz, hipMemcpyDeviceToHost, ctx->impl->stream));
+        HIPCHK(hipStreamSynchronize(ctx->impl->stream));
+    }
+    return NRS_OK;
+}
+int nrs_device_ptr(nrs_ctx *ctx, int which, void **dptr, uint64_t *bytes)
+{
+    CTX_GUARD(ctx);
+    if (!dptr || !bytes) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->array(which, dptr, bytes);
+}
+int nrs_last_iterations(nrs_ctx *ctx, uint32_t *iters)
+{
+    CTX_GUARD(ctx);
+    if (!iters) return fail(NRS_E_INVALID, "NULL argument");
+    *iters = ctx->impl->lastIters;
+    return NRS_OK;
+}
+int nrs_set_max_iterations(nrs_ctx *ctx, uint32_t max_iters)
+{
+    CTX_GUARD(ctx);
+    ctx->impl->maxIters = max_iters;
+    return NRS_OK;
+}
+int nrs_set_profiling(nrs_ctx *ctx, uint32_t stage_mask)
+{
+    CTX_GUARD(ctx);
+    ctx->impl->profMask = stage_mask;
+    return NRS_OK;
+}
+int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches)
+{
+    CTX_GUARD(ctx);
+    if (!ms) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->stage_ms(stage, ms, launches);
+}
+int nrs_max_density(nrs_ctx *ctx, double *out)
+{
+    CTX_GUARD(ctx);
+    if (!out) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->reduce_max(0, out);
+}
+int nrs_max_velocity(nrs_ctx *ctx, double *out)
+{
+    CTX_GUARD(ctx);
+    if (!out) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->reduce_max(1, out);
+}
+
+} // extern "C"

@@ -1,0 +1,734 @@
+// nrs_kernels_ref.h — "reference-order" gfx950 kernels for the SPH step.
+//
+// One thread per SORTED slot (coalesced own loads/stores; the reference's thread→slot indirection
+// through gridParticleIndex is dropped), the 27 neighbour cells walked z,y,x with j ascending
+// and one partial sum per cell, i.e. every floating-point sum is formed in the order the reference forms
+// it.  Selected with NRS_FLAG_REFERENCE_ORDER; used for bit-level comparison with the oracle and as the
+// semantic definition the tiled kernels (nrs_kernels_tiled.h) are checked against.
+//
+// What each kernel computes is specified by the reference kernel cited above it; none of the reference's
+// source is reproduced here.
+#pragma once
+#include "nrs_math.h"
+
+namespace nrs {
+
+template <typename R> struct GridView {
+    typedef typename Vec4T<R>::type T4;
+    const uint32_t *cellStart, *cellEnd;   // fluid cell table
+    const uint32_t *bCellStart, *bCellEnd; // boundary cell table (valid only when the kernel has HAS_B)
+    const T4 *sB;                          // sorted boundary particles: xyz + Vbi in w
+};
+
+constexpr int BLOCK = 256;
+
+// ---- calcHashD (sph_kernel_impl.cuh:127-145) -------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_hash(Params<R> P, const typename Vec4T<R>::type *__restrict__ pos,
+                                                uint32_t *__restrict__ hash, uint32_t *__restrict__ index, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    I3 g = calcGridPos<R>(P, xyz<R>(pos[i]));
+    hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
+    index[i] = i;
+}
+
+// ---- reorderDataAndFindCellStartD (sph_kernel_impl.cuh:210-281) -------------------------------------
+// cellStart must have been filled with 0xff.  Also emits inv[index[i]] = i (needed for SURVEY Q5).
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ hash, const uint32_t *__restrict__ index,
+                                                   const typename Vec4T<R>::type *__restrict__ oldPos,
+                                                   const typename Vec4T<R>::type *__restrict__ oldVel,
+                                                   const R *__restrict__ oldPres,
+                                                   typename Vec4T<R>::type *__restrict__ sPos,
+                                                   typename Vec4T<R>::type *__restrict__ sVel, R *__restrict__ sPres,
+                                                   uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
+                                                   uint32_t *__restrict__ inv, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = hash[i];
+    if (i == 0) {
+        cellStart[h] = 0;
+    } else {
+        const uint32_t hp = hash[i - 1];
+        if (h != hp) { cellStart[h] = i; cellEnd[hp] = i; }
+    }
+    if (i == n - 1) cellEnd[h] = n;
+    const uint32_t src = index[i];
+    sPos[i] = oldPos[src];
+    sVel[i] = oldVel[src];
+    if (oldPres) sPres[i] = oldPres[src];
+    if (inv) inv[src] = i;
+}
+
+// boundary flavour (sph_kernel_impl.cuh:150-205, intended semantics — SURVEY Q1): sorted xyz + vbi packed in one vec4
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_reorder_boundary(const uint32_t *__restrict__ hash,
+                                                            const uint32_t *__restrict__ index,
+                                                            const typename Vec4T<R>::type *__restrict__ bi,
+                                                            const R *__restrict__ vbi,
+                                                            typename Vec4T<R>::type *__restrict__ sB,
+                                                            uint32_t *__restrict__ cellStart,
+                                                            uint32_t *__restrict__ cellEnd, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = hash[i];
+    if (i == 0) {
+        cellStart[h] = 0;
+    } else {
+        const uint32_t hp = hash[i - 1];
+        if (h != hp) { cellStart[h] = i; cellEnd[hp] = i; }
+    }
+    if (i == n - 1) cellEnd[h] = n;
+    const uint32_t src = index[i];
+    typename Vec4T<R>::type b = bi[src];
+    b.w = vbi[src];
+    sB[i] = b;
+}
+
+// ---- density sum shared by computeDensityPressure (:365-433) and computeIisphDensity (:770-846) ----
+template <typename R, int KSET, bool HAS_B>
+NRS_DEV R density_of(const Params<R> &P, const GridView<R> &G, const typename Vec4T<R>::type *__restrict__ sPos,
+                     uint32_t self)
+{
+    const V3<R> p = xyz<R>(sPos[self]);
+    const I3 gp = calcGridPos<R>(P, p);
+    const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
+    R dens = (R)0.0;
+    dens += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                {
+                    R c = (R)0.0;
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j != self) {
+                                const V3<R> d = p - xyz<R>(sPos[j]);
+                                if (length(d) < ir) c += (pm * W_dens<R, KSET>(d, ir, kp));
+                            }
+                        }
+                    }
+                    dens += c;
+                }
+                if (HAS_B) {
+                    R c = (R)0.0;
+                    const uint32_t s = G.bCellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.bCellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = p - xyz<R>(b);
+                            if (length(d) < ir) {
+                                const R psi = rd * b.w;
+                                c += (psi * W_dens<R, KSET>(d, ir, kp));
+                            }
+                        }
+                    }
+                    dens += c;
+                }
+            }
+    return dens;
+}
+
+// Tait equation of state (sph_kernel_impl.cuh:426)
+template <typename R> NRS_DEV R tait_pressure(const Params<R> &P, R dens)
+{
+    return P.gasStiffness * (pow7f((float)(dens / P.restDensity)) - 1);
+}
+
+template <typename R, int KSET, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_density_ref(Params<R> P, GridView<R> G,
+                                                       const typename Vec4T<R>::type *__restrict__ sPos,
+                                                       R *__restrict__ dens, R *__restrict__ pres, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const R d = density_of<R, KSET, HAS_B>(P, G, sPos, i);
+    dens[i] = d;
+    if (pres) pres[i] = tait_pressure<R>(P, d);
+}
+
+// ---- computeCellForces (sph_kernel_impl.cuh:442-604) -------------------------------------------------
+template <typename R> struct ForceAcc { V3<R> fpres, fvisc, fsurf, fbound; };
+
+template <typename R, int KSET, bool SURF, bool HAS_B>
+NRS_DEV void cell_forces(const Params<R> &P, const GridView<R> &G, ForceAcc<R> &A, uint32_t h, uint32_t self,
+                         V3<R> pos1, V3<R> vel1, R dens, R pres, const typename Vec4T<R>::type *__restrict__ sPos,
+                         const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
+                         const R *__restrict__ sPres)
+{
+    const R pm = P.particleMass, m2 = P.particleMass, ir = P.interactionRadius, kp = P.kpoly;
+    const R kappa = P.surfaceTension;
+    const R kprg = P.kpress_grad, kvg = P.kvisc_grad, kvd = P.kvisc_denum;
+    uint32_t s = G.cellStart[h];
+    if (s != CELL_EMPTY) {
+        const uint32_t e = G.cellEnd[h];
+        for (uint32_t j = s; j < e; ++j) {
+            if (j == self) continue;
+            const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
+            if (length(p1p2) < ir) {
+                const R dens2 = sDens[j];
+                const R pres2 = sPres[j];
+                const V3<R> vel2 = xyz<R>(sVel[j]);
+                const R diameter = (R)(2.0 * P.particleRadius);
+                const R diameter2 = diameter * diameter;
+                const V3<R> v1v2 = vel1 - vel2;
+                const R d1sq = dens * dens;
+                const R d2sq = dens2 * dens2;
+                V3<R> kpressure_grad, kvisco_grad;
+                R kernel, kernel_diameter;
+                if (KSET == KS_MONAGHAN) {
+                    kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
+                    kvisco_grad = kpressure_grad;
+                    kernel = Wmonaghan<R>(p1p2, ir);
+                    kernel_diameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
+                } else {
+                    kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
+                    kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
+                    kernel = Wdefault<R>(p1p2, ir, kp);
+                    kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
+                }
+                A.fpres = A.fpres + (m2 * (pres / d1sq + pres2 / d2sq) * kpressure_grad);
+                const R a = dot(p1p2, kvisco_grad);
+                const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
+                A.fvisc = A.fvisc + (m2 / dens2 * v1v2 * (a / b));
+                if (SURF) {
+                    V3<R> ai = mk3<R>(0, 0, 0);
+                    const R r2 = dot(p1p2, p1p2);
+                    if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
+                    else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+                    A.fsurf = A.fsurf + ai;
+                }
+            }
+        }
+    }
+    if (HAS_B) {
+        s = G.bCellStart[h];
+        const R epsilon = (R)0.01;
+        const R beta = P.beta;
+        const R rd = P.restDensity;
+        if (s != CELL_EMPTY) {
+            const uint32_t e = G.bCellEnd[h];
+            for (uint32_t j = s; j < e; ++j) { // no distance test on boundary particles (as the reference)
+                const typename Vec4T<R>::type bq = G.sB[j];
+                const R vbi = bq.w;
+                const V3<R> vpos = xyz<R>(bq);
+                const R psi = (rd * vbi);
+                const V3<R> p1p2 = pos1 - vpos;
+                const V3<R> v1v2 = vel1;
+                R kernel;
+                V3<R> grad;
+                if (KSET == KS_MONAGHAN) {
+                    kernel = Wmonaghan<R>(p1p2, ir);
+                    grad = Wmonaghan_grad<R>(p1p2, ir);
+                } else {
+                    kernel = Wdefault<R>(p1p2, ir, P.kpoly);
+                    grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+                }
+                A.fbound = A.fbound + (beta * psi * p1p2 * kernel);
+                A.fpres = A.fpres + (-pm * psi * (pres / (dens * dens)) * grad);
+                const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
+                const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
+                const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
+                const R Pij = -nu * (nom / denom);
+                A.fvisc = A.fvisc - (pm * psi * Pij * grad);
+            }
+        }
+    }
+}
+
+template <typename R, int KSET, bool SURF, bool HAS_B>
+NRS_DEV ForceAcc<R> gather_forces(const Params<R> &P, const GridView<R> &G, uint32_t self, V3<R> pos, V3<R> vel, R dens,
+                                  R pres, const typename Vec4T<R>::type *__restrict__ sPos,
+                                  const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
+                                  const R *__restrict__ sPres)
+{
+    ForceAcc<R> A;
+    A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
+    const I3 gp = calcGridPos<R>(P, pos);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                cell_forces<R, KSET, SURF, HAS_B>(P, G, A, h, self, pos, vel, dens, pres, sPos, sVel, sDens, sPres);
+            }
+    return A;
+}
+
+// final combination of computeForces (sph_kernel_impl.cuh:663-674)
+template <typename R> NRS_DEV V3<R> sesph_total_force(const Params<R> &P, ForceAcc<R> A, R dens)
+{
+    const R m1 = P.particleMass;
+    V3<R> fpres = A.fpres * dens;
+    V3<R> fvisc = A.fvisc * 2.0;
+    fpres = fpres * -(m1 / dens);
+    fvisc = fvisc * (m1 * P.viscosity);
+    const V3<R> grav = mk3<R>(P.gravity[0], P.gravity[1], P.gravity[2]);
+    return fpres + fvisc + (grav * m1) + A.fsurf + A.fbound;
+}
+
+// ---- computeForces (sph_kernel_impl.cuh:609-680) -----------------------------------------------------
+template <typename R, int KSET, bool SURF, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_forces_ref(Params<R> P, GridView<R> G,
+                                                      const typename Vec4T<R>::type *__restrict__ sPos,
+                                                      const typename Vec4T<R>::type *__restrict__ sVel,
+                                                      const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                      typename Vec4T<R>::type *__restrict__ forces, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos = xyz<R>(sPos[i]);
+    const V3<R> vel = xyz<R>(sVel[i]);
+    const R dens = sDens[i], pres = sPres[i];
+    ForceAcc<R> A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos, vel, dens, pres, sPos, sVel, sDens, sPres);
+    const V3<R> f = sesph_total_force<R>(P, A, dens);
+    forces[i] = mk4<R>(f, (R)0);
+}
+
+// ---- integrate_functor (sph_kernel_impl.cuh:71-100): symplectic Euler, w components kept --------------
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_integrate(Params<R> P, typename Vec4T<R>::type *__restrict__ pos,
+                                                     typename Vec4T<R>::type *__restrict__ vel,
+                                                     const typename Vec4T<R>::type *__restrict__ forces, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const R dt = P.timestep, m1 = P.particleMass;
+    typename Vec4T<R>::type p4 = pos[i], v4 = vel[i];
+    V3<R> p = xyz<R>(p4), v = xyz<R>(v4), frc = xyz<R>(forces[i]);
+    const V3<R> accel = dt * frc / m1;
+    v = v + accel;
+    p = p + dt * v;
+    pos[i] = mk4<R>(p, p4.w);
+    vel[i] = mk4<R>(v, v4.w);
+}
+
+// =========================================== IISPH ====================================================
+template <typename R> struct IisphArrays {
+    typedef typename Vec4T<R>::type T4;
+    R *densAdv, *densCorr, *P_l, *P_l_next, *aii;
+    T4 *velAdv, *forcesAdv, *forcesP, *diiF, *diiB, *sumDij;
+    const uint32_t *inv; // inv[slot] = id of the reference thread that handles the slot
+};
+
+// computeIisphDensity (:770-846) is k_density_ref with pres == nullptr.
+
+// computeDisplacementFactor (sph_kernel_impl.cuh:851-963) + its two cell helpers (:689-765)
+template <typename R, int KSET, bool SURF, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_displacement_ref(Params<R> P, GridView<R> G, IisphArrays<R> I,
+                                                            const typename Vec4T<R>::type *__restrict__ sPos,
+                                                            const typename Vec4T<R>::type *__restrict__ sVel,
+                                                            const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                            uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const V3<R> vel1 = xyz<R>(sVel[i]);
+    const R pres = (R)0.0;
+    const R dens = sDens[i];
+    const R kpg = P.kpoly_grad, pm = P.particleMass, ir = P.interactionRadius, rd = P.restDensity, dt = P.timestep;
+    ForceAcc<R> A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
+    V3<R> fvisc = 2.0 * A.fvisc;
+    fvisc = (pm * P.viscosity) * fvisc;
+    const V3<R> fgrav = pm * mk3<R>(P.gravity[0], P.gravity[1], P.gravity[2]);
+    const V3<R> force_adv = fvisc + A.fsurf + A.fbound + fgrav;
+    const V3<R> vel_adv = vel1 + dt * (force_adv / pm);
+    I.forcesAdv[i] = mk4<R>(force_adv, (R)0.0);
+    I.velAdv[i] = mk4<R>(vel_adv, (R)0.0);
+
+    const I3 gp = calcGridPos<R>(P, pos1);
+    V3<R> df = mk3<R>(0, 0, 0), db = mk3<R>(0, 0, 0);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                {
+                    V3<R> res = mk3<R>(0, 0, 0);
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            if (length(d) < ir) {
+                                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                                res = res - ((pm / (dens * dens)) * grad);
+                            }
+                        }
+                    }
+                    df = df + res;
+                }
+                if (HAS_B) {
+                    V3<R> res = mk3<R>(0, 0, 0);
+                    const uint32_t s = G.bCellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.bCellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const R psi = rd * b.w;
+                            if (length(d) < ir) {
+                                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                                res = res - ((psi / (dens * dens)) * grad);
+                            }
+                        }
+                    }
+                    db = db + res;
+                }
+            }
+    I.diiF[i] = mk4<R>(df, (R)0.0);
+    I.diiB[i] = mk4<R>(db, (R)0.0);
+}
+
+// computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) + helpers (:968-1108)
+template <typename R, int KSET, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_advection_ref(Params<R> P, GridView<R> G, IisphArrays<R> I,
+                                                         const typename Vec4T<R>::type *__restrict__ sPos,
+                                                         const typename Vec4T<R>::type *__restrict__ sVel,
+                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                         uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const V3<R> vel1 = xyz<R>(sVel[i]);
+    const V3<R> velAdv1 = xyz<R>(I.velAdv[i]);
+    const R dens = sDens[i];
+    const V3<R> diif = xyz<R>(I.diiF[i]);
+    const V3<R> diib = xyz<R>(I.diiB[i]);
+    const I3 gp = calcGridPos<R>(P, pos1);
+    const R kpg = P.kpoly_grad, pm = P.particleMass, ir = P.interactionRadius, rd = P.restDensity, dt = P.timestep;
+
+    R rho_advf = (R)0.0, rho_advb = (R)0.0;
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                {
+                    R res = (R)0.0;
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> velAdv2 = xyz<R>(I.velAdv[j]);
+                            const V3<R> v1v2 = velAdv1 - velAdv2;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            if (length(d) < ir) {
+                                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                                res += (dt * pm * dot(v1v2, grad));
+                            }
+                        }
+                    }
+                    rho_advf += res;
+                }
+                if (HAS_B) {
+                    R res = (R)0.0;
+                    const uint32_t s = G.bCellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.bCellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) { // no cut-off: relies on W_grad == 0 beyond h (Q8)
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const V3<R> v1v2 = vel1;
+                            const R psi = (rd * b.w);
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            res += (dt * psi * dot(v1v2, grad));
+                        }
+                    }
+                    rho_advb += res;
+                }
+            }
+    const R rho_adv = dens + (rho_advf + rho_advb);
+    I.densAdv[i] = rho_adv;
+    I.P_l[i] = (R)(0.5 * sPres[i]);
+
+    R aii = (R)0.0;
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                {
+                    R res = (R)0.0;
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            const R dpi = (pm) / (dens * dens);
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            const V3<R> dji = dpi * grad;
+                            res += (pm * dot((diif + diib) - dji, grad));
+                        }
+                    }
+                    aii += res;
+                }
+                if (HAS_B) {
+                    R res = (R)0.0;
+                    const uint32_t s = G.bCellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.bCellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const R psi = rd * b.w;
+                            const R dpi = (pm) / (dens * dens);
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            const V3<R> dji = dpi * grad;
+                            res += psi * dot((diif + diib) - dji, grad);
+                        }
+                    }
+                    aii += res;
+                }
+            }
+    I.aii[i] = aii;
+}
+
+// computeSumDijPj (sph_kernel_impl.cuh:1259-1325) + dijpjcell (:1224-1253)
+template <typename R, int KSET>
+__global__ __launch_bounds__(BLOCK) void k_sumdij_ref(Params<R> P, GridView<R> G, IisphArrays<R> I,
+                                                      const typename Vec4T<R>::type *__restrict__ sPos,
+                                                      const R *__restrict__ sDens, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const I3 gp = calcGridPos<R>(P, pos1);
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad;
+    V3<R> dijpj = mk3<R>(0, 0, 0);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                V3<R> res = mk3<R>(0, 0, 0);
+                const uint32_t s = G.cellStart[h];
+                if (s != CELL_EMPTY) {
+                    const uint32_t e = G.cellEnd[h];
+                    for (uint32_t j = s; j < e; ++j) {
+                        if (j == i) continue;
+                        const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                        const R p_lj = I.P_l[j];
+                        const R densj = sDens[j];
+                        const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                        res = res - ((pm / (densj * densj)) * p_lj * grad);
+                    }
+                }
+                dijpj = dijpj + res;
+            }
+    I.sumDij[i] = mk4<R>(dijpj, (R)0.0);
+}
+
+// computePressure (sph_kernel_impl.cuh:1330-1492): relaxed Jacobi, omega = 0.5.
+// Q5: the fluid loop skips j == inv[i] (the reference thread id), not j == i.
+// Q6: the boundary loop runs j from the FLUID cell start to the boundary cell end.
+// Q7: reads P_l, writes P_l_next (true Jacobi; the reference updates in place and races).
+template <typename R, int KSET, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_pressure_ref(Params<R> P, GridView<R> G, IisphArrays<R> I,
+                                                        const typename Vec4T<R>::type *__restrict__ sPos,
+                                                        const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t skip = I.inv[i];
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const R dens = sDens[i];
+    R p_l = I.P_l[i];
+    const R previous_p_l = p_l;
+    const R rho_adv = I.densAdv[i];
+    const R aii = I.aii[i];
+    const V3<R> dijpj = xyz<R>(I.sumDij[i]);
+    const I3 gp = calcGridPos<R>(P, pos1);
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad, dt = P.timestep, rd = P.restDensity;
+    R fsum = (R)0.0, bsum = (R)0.0;
+    const R dpi = pm / (dens * dens);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                const uint32_t s = G.cellStart[h];
+                if (s != CELL_EMPTY) {
+                    const uint32_t e = G.cellEnd[h];
+                    for (uint32_t j = s; j < e; ++j) {
+                        if (j == skip) continue;
+                        const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                        const R p_lj = I.P_l[j];
+                        const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                        const V3<R> dji = dpi * (grad);
+                        const V3<R> d_ji_pi = dji * p_lj;
+                        const V3<R> diifj = xyz<R>(I.diiF[j]);
+                        const V3<R> diibj = xyz<R>(I.diiB[j]);
+                        const V3<R> sum_dijj = xyz<R>(I.sumDij[j]);
+                        fsum += pm * dot(dijpj - (diifj + diibj) * p_lj - (sum_dijj - d_ji_pi), grad);
+                    }
+                }
+                if (HAS_B) {
+                    const uint32_t sB = G.bCellStart[h];
+                    if (sB != CELL_EMPTY) {
+                        const uint32_t eB = G.bCellEnd[h];
+                        for (uint32_t j = s; j < eB; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const R psi = rd * b.w;
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            bsum += psi * dot(dijpj, grad);
+                        }
+                    }
+                }
+            }
+    const R omega = (R)0.5;
+    R rho_corr = rho_adv + fsum + bsum;
+    const R dt2 = dt * dt;
+    const R denom = aii * dt2;
+    const R b = rd - rho_adv;
+    if (fabs(denom) > 1.1920928955078125e-07f /* FLT_EPSILON */)
+        p_l = (R)((1.0 - omega) * previous_p_l + (omega / denom) * (b - dt2 * (bsum + fsum)));
+    else
+        p_l = (R)0.0;
+    const R p = (R)fmax((double)p_l, 0.0);
+    p_l = p;
+    rho_corr += aii * previous_p_l;
+    I.P_l_next[i] = p_l;
+    sPres[i] = p_l;
+    I.densCorr[i] = rho_corr;
+}
+
+// computePressureForce (sph_kernel_impl.cuh:1497-1620), same Q5/Q6
+template <typename R, int KSET, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_pforce_ref(Params<R> P, GridView<R> G, IisphArrays<R> I,
+                                                      const typename Vec4T<R>::type *__restrict__ sPos,
+                                                      const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                      uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t skip = I.inv[i];
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const R p = sPres[i];
+    const R dens = sDens[i];
+    const I3 gp = calcGridPos<R>(P, pos1);
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad, rd = P.restDensity;
+    V3<R> fp = mk3<R>(0, 0, 0);
+    for (int z = -1; z <= 1; z++)
+        for (int y = -1; y <= 1; y++)
+            for (int x = -1; x <= 1; x++) {
+                const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                const uint32_t s = G.cellStart[h];
+                if (s != CELL_EMPTY) {
+                    const uint32_t e = G.cellEnd[h];
+                    for (uint32_t j = s; j < e; ++j) {
+                        if (j == skip) continue;
+                        const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                        const R pj = sPres[j];
+                        const R densj = sDens[j];
+                        const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                        const V3<R> contrib = -pm * pm * (p / (dens * dens) + pj / (densj * densj)) * grad;
+                        fp = fp + contrib;
+                    }
+                }
+                if (HAS_B) {
+                    const uint32_t sB = G.bCellStart[h];
+                    if (sB != CELL_EMPTY) {
+                        const uint32_t eB = G.bCellEnd[h];
+                        for (uint32_t j = s; j < eB; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const R psi = rd * b.w;
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            const V3<R> contrib = (pm * psi * (p / (dens * dens)) * grad);
+                            fp = fp + contrib;
+                        }
+                    }
+                }
+            }
+    I.forcesP[i] = mk4<R>(fp, (R)0.0);
+}
+
+// iisph_integrate (sph_kernel_impl.cuh:1625-1655): sets pos.w = 1, vel.w = 0
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename Vec4T<R>::type *__restrict__ pos,
+                                                           typename Vec4T<R>::type *__restrict__ vel,
+                                                           const typename Vec4T<R>::type *__restrict__ velAdv,
+                                                           const typename Vec4T<R>::type *__restrict__ forcesP,
+                                                           uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const R dt = P.timestep, pm = P.particleMass;
+    const V3<R> pos1 = xyz<R>(pos[i]);
+    const V3<R> velAdv1 = xyz<R>(velAdv[i]);
+    const V3<R> fpres1 = xyz<R>(forcesP[i]);
+    const V3<R> newVel = velAdv1 + (dt * fpres1 / pm);
+    const V3<R> newPos = pos1 + (dt * newVel);
+    pos[i] = mk4<R>(newPos, (R)1.0);
+    vel[i] = mk4<R>(newVel, (R)0.0);
+}
+
+// deterministic two-pass sum of an SReal array in double (replaces thrust::reduce, sph_cuda.cu:816-819)
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_sum_partial(const R *__restrict__ a, double *__restrict__ partial, uint32_t n)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = 0.0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) acc += (double)a[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_sum_final(const double *__restrict__ partial, double *__restrict__ out,
+                                                     uint32_t nblocks)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += BLOCK) acc += partial[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += sm[w];
+        *out = t;
+    }
+}
+
+// max of an SReal array / of |v| over a vec4 array (maxDensity / maxVelocity, sph_cuda.cu:32-53)
+template <typename R, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_max_partial(const void *__restrict__ a, double *__restrict__ partial,
+                                                       uint32_t n)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = -1.0e300;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        double v;
+        if (VEC) {
+            typename Vec4T<R>::type q = ((const typename Vec4T<R>::type *)a)[i];
+            v = sqrt((double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z);
+        } else {
+            v = (double)((const R *)a)[i];
+        }
+        acc = fmax(acc, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc = fmax(acc, __shfl_down(acc, off, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sm[0];
+        for (int w = 1; w < BLOCK / 64; ++w) t = fmax(t, sm[w]);
+        partial[blockIdx.x] = t;
+    }
+}
+
+} // namespace nrs

@@ -1,0 +1,176 @@
+// nrs_math.h — device-side vector layer and smoothing kernels for the gfx950 SPH step.
+//
+// Semantics to match (not code): the reference's helper_math.h overload set
+// (common/cuda_helpers/helper_math.h:817-829, 1000-1008, 1251-1301) takes and returns *float* scalars
+// even when SVec3 is double3, and common/kernels_impl.cuh:85-203 mixes pow/powf.
+// All arithmetic is IEEE (this file is compiled with -ffp-contract=off; division and sqrt are the
+// correctly rounded forms), so the fp32 path can be compared bit-for-bit with the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrs {
+
+#define NRS_DEV __device__ __forceinline__
+#define NRS_HD __host__ __device__ __forceinline__
+
+template <typename R> struct V3 { R x, y, z; };
+
+template <typename R> struct Vec4T;
+template <> struct Vec4T<float> { typedef float4 type; };
+template <> struct Vec4T<double> { typedef double4 type; };
+
+template <typename R> NRS_DEV V3<R> mk3(R x, R y, R z) { V3<R> v; v.x = x; v.y = y; v.z = z; return v; }
+template <typename R, typename T4> NRS_DEV V3<R> xyz(const T4 &a) { return mk3<R>(a.x, a.y, a.z); }
+template <typename R> NRS_DEV typename Vec4T<R>::type mk4(R x, R y, R z, R w)
+{
+    typename Vec4T<R>::type v; v.x = x; v.y = y; v.z = z; v.w = w; return v;
+}
+template <typename R> NRS_DEV typename Vec4T<R>::type mk4(V3<R> a, R w) { return mk4<R>(a.x, a.y, a.z, w); }
+
+template <typename R> NRS_DEV V3<R> operator+(V3<R> a, V3<R> b) { return mk3<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> NRS_DEV V3<R> operator-(V3<R> a, V3<R> b) { return mk3<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+// scalar operands are float by signature, as in the reference
+template <typename R> NRS_DEV V3<R> operator*(V3<R> a, float b) { return mk3<R>(a.x * b, a.y * b, a.z * b); }
+template <typename R> NRS_DEV V3<R> operator*(float b, V3<R> a) { return mk3<R>(b * a.x, b * a.y, b * a.z); }
+template <typename R> NRS_DEV V3<R> operator/(V3<R> a, float b) { return mk3<R>(a.x / b, a.y / b, a.z / b); }
+template <typename R> NRS_DEV float dot(V3<R> a, V3<R> b) { return (float)(a.x * b.x + a.y * b.y + a.z * b.z); }
+NRS_DEV float sqrt_rn(float x) { return __fsqrt_rn(x); }
+template <typename R> NRS_DEV float length(V3<R> v) { return sqrt_rn(dot(v, v)); }
+
+// x^3 the way g++ evaluates pow(SReal,int): in double, rounded once to SReal (kernels_impl.cuh:95)
+template <typename R> NRS_DEV R cube_via_double(R x) { double d = (double)x; return (R)(d * d * d); }
+// powf(x,2) (kernels_impl.cuh:113): float square, also in fp64 builds
+template <typename R> NRS_DEV R square_via_float(R x) { float f = (float)x; return (R)(f * f); }
+// powf(x,7) (sph_kernel_impl.cuh:426): float result of x^7; computed in double and rounded once
+NRS_DEV float pow7f(float x)
+{
+    double d = (double)x, d2 = d * d, d4 = d2 * d2;
+    return (float)(d4 * d2 * d);
+}
+
+enum { KS_MONAGHAN = 0, KS_MULLER = 1 };
+
+// Muller poly6 W (kernels_impl.cuh:85-98)
+template <typename R> NRS_DEV R Wdefault(V3<R> r, R h, R kpoly)
+{
+    R r2 = length(r) * length(r);
+    R h2 = h * h;
+    if (r2 > h2) return (R)0.0;
+    R b = cube_via_double<R>(h2 - r2);
+    return kpoly * b;
+}
+// gradient of poly6 (:103-116)
+template <typename R> NRS_DEV V3<R> Wdefault_grad(V3<R> r, R h, R kpoly_grad)
+{
+    R r2 = length(r) * length(r);
+    R h2 = h * h;
+    if (r2 > h2) return mk3<R>(0, 0, 0);
+    R b = square_via_float<R>(h2 - r2);
+    return kpoly_grad * r * b;
+}
+// spiky gradient (:121-135)
+template <typename R> NRS_DEV V3<R> Wpressure_grad(V3<R> r, R h, R kpress_grad)
+{
+    R l_r = length(r);
+    R r2 = l_r * l_r;
+    R h2 = h * h;
+    if (r2 > h2) return mk3<R>(0, 0, 0);
+    R c = (h - l_r) * (h - l_r);
+    return kpress_grad * (r / l_r) * c;
+}
+// viscosity kernel "gradient" (:140-154)
+template <typename R> NRS_DEV V3<R> Wviscosity_grad(V3<R> r, R h, R kvisc_grad, R kvisc_denum)
+{
+    R l_r = length(r);
+    R r2 = l_r * l_r;
+    R h2 = h * h;
+    if (r2 > h2) return mk3<R>(0, 0, 0);
+    R c = -(3 * l_r / kvisc_denum) + (2 / (h2)) - (h / (2 * l_r * l_r * l_r));
+    return kvisc_grad * r * c;
+}
+// Monaghan cubic spline (:159-203); constants evaluated in double as the host compiler does
+template <typename R> NRS_DEV R Wmonaghan(V3<R> r, R h)
+{
+    R value = (R)0.0;
+    R m_invH = (R)(1.0 / h);
+    R m_v = (R)(1.0 / (4.0 * 3.14159265358979323846 * h * h * h));
+    R q = length(r) * m_invH;
+    if (q >= 0 && q < 1)
+        value = m_v * ((2 - q) * (2 - q) * (2 - q) - 4.0f * (1 - q) * (1 - q) * (1 - q));
+    else if (q >= 1 && q < 2)
+        value = m_v * ((2 - q) * (2 - q) * (2 - q));
+    else
+        value = 0.0f;
+    return value;
+}
+template <typename R> NRS_DEV V3<R> Wmonaghan_grad(V3<R> r, R h)
+{
+    R m_g = (R)(1.0 / (4.0 * 3.14159265358979323846 * h * h * h));
+    R dist = length(r);
+    R m_invH = (R)(1.0 / h);
+    R q = dist * m_invH;
+    V3<R> gradient = mk3<R>(0, 0, 0);
+    if (q >= 0 && q < 1) {
+        R scalar = -3.0f * (2 - q) * (2 - q);
+        scalar += 12.0f * (1 - q) * (1 - q);
+        gradient = (m_g * m_invH * scalar / dist) * r;
+    } else if (q >= 1 && q < 2) {
+        R scalar = -3.0f * (2 - q) * (2 - q);
+        gradient = (m_g * scalar * m_invH / dist) * r;
+    }
+    return gradient;
+}
+
+template <typename R, int KSET> NRS_DEV R W_dens(V3<R> r, R ir, R kp)
+{
+    if (KSET == KS_MULLER) return Wdefault<R>(r, ir, kp);
+    return Wmonaghan<R>(r, ir);
+}
+template <typename R, int KSET> NRS_DEV V3<R> W_grad(V3<R> r, R ir, R kpg)
+{
+    if (KSET == KS_MULLER) return Wdefault_grad<R>(r, ir, kpg);
+    return Wmonaghan_grad<R>(r, ir);
+}
+
+// SphSimParams, byte-identical to nrs_params_f32 / nrs_params_f64 (include/nereus_hip.h)
+template <typename R> struct Params {
+    uint32_t gridSize[3];
+    uint32_t numCells;
+    R worldOrigin[3];
+    R cellSize[3];
+    uint32_t numBodies;
+    uint32_t maxParticlesPerCell;
+    R gasStiffness, viscosity, surfaceTension, restDensity, particleMass, interactionRadius, timestep, particleRadius;
+    R gravity[3];
+    R soundSpeed;
+    R beta;
+    R kpoly, kpoly_grad, kpress_grad, kvisc_grad, kvisc_denum, ksurf1, ksurf2, bpol;
+};
+static_assert(sizeof(Params<float>) == 132, "fp32 SphSimParams must be 132 bytes");
+static_assert(sizeof(Params<double>) == 240, "fp64 SphSimParams must be 240 bytes");
+
+struct I3 { int x, y, z; };
+
+// calcGridPos (sph_kernel_impl.cuh:105-113): true division, then floor
+template <typename R> NRS_DEV I3 calcGridPos(const Params<R> &P, V3<R> p)
+{
+    I3 g;
+    g.x = (int)floor((p.x - P.worldOrigin[0]) / P.cellSize[0]);
+    g.y = (int)floor((p.y - P.worldOrigin[1]) / P.cellSize[1]);
+    g.z = (int)floor((p.z - P.worldOrigin[2]) / P.cellSize[2]);
+    return g;
+}
+NRS_DEV uint32_t umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+// calcGridHash (:118-125): power-of-two wrap, 24-bit multiplies
+template <typename R> NRS_DEV uint32_t calcGridHash(const Params<R> &P, int gx, int gy, int gz)
+{
+    uint32_t x = (uint32_t)gx & (P.gridSize[0] - 1);
+    uint32_t y = (uint32_t)gy & (P.gridSize[1] - 1);
+    uint32_t z = (uint32_t)gz & (P.gridSize[2] - 1);
+    return umul24(umul24(z, P.gridSize[1]), P.gridSize[0]) + umul24(y, P.gridSize[0]) + x;
+}
+
+static constexpr uint32_t CELL_EMPTY = 0xffffffffu;
+
+} // namespace nrs

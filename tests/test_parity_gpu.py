@@ -1,0 +1,304 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): hash / index / cell tables bit-exact; fp32 state within 1e-5 relative
+after N steps.  Per-stage float arrays are compared much tighter than that (see TOL_* below): the HIP
+kernels form every sum in the reference's order with IEEE arithmetic, so differences can only come from
+the last-bit behaviour of pow()/powf().
+"""
+import os
+
+import numpy as np
+import pytest
+
+from nereus_amd import capi, scene
+from tests.common import check_cell_tables, compressed_block, default_scene, rel_err, small_dam_break
+from tests.oracle_lib import (IISPH, SESPH, STOP_DENSITY, STOP_FORCES, STOP_HASH, STOP_I_ADVECTION,
+                              STOP_I_DISPLACEMENT, STOP_I_PFORCE, STOP_I_SOLVE, STOP_REORDER, STOP_SORT, Oracle)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_STAGE = 2e-6   # per-stage float arrays (density, pressure, forces, IISPH intermediates), array-relative
+TOL_STEPS = 1e-5   # positions / velocities after N steps (the north_star bar)
+
+
+def make_pair(p, pos, vel, bi=None, vbi=None, solver=SESPH, double=False, kset=1, ref=False, pres=None,
+              capacity=None):
+    o = Oracle(p, double, kset, solver)
+    o.set_particles(pos, vel, pres)
+    o.set_boundaries(bi, vbi, update_grid=True)
+    s = capi.Solver(p, capacity or max(len(pos), 1), solver=solver, double=double, kernel_set=kset,
+                    reference_order=ref)
+    s.set_particles(pos, vel, pres)
+    s.set_boundaries(bi, vbi, update_grid=True)
+    return o, s
+
+
+@pytest.mark.parametrize("ref", [False, True], ids=["tiled", "reforder"])
+def test_sesph_stages_default_scene(hip_lib, ref):
+    p, pos, vel = default_scene(SESPH)
+    o, s = make_pair(p, pos, vel, ref=ref)
+    # hash (unsorted)
+    o.step(1, stop=STOP_HASH); s.step_partial(capi.STAGE_HASH)
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    np.testing.assert_array_equal(s.get("index"), np.arange(len(pos), dtype=np.uint32))
+    # sort
+    s.set_particles(pos, vel)
+    o.step(1, stop=STOP_SORT); s.step_partial(capi.STAGE_SORT)
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    np.testing.assert_array_equal(s.get("index"), o.get("index"))
+    # reorder + cell tables
+    s.set_particles(pos, vel)
+    o.step(1, stop=STOP_REORDER); s.step_partial(capi.STAGE_REORDER)
+    check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
+    np.testing.assert_array_equal(s.get("sortedPos"), o.get("sortedPos"))
+    np.testing.assert_array_equal(s.get("sortedVel"), o.get("sortedVel"))
+    # density / pressure
+    s.set_particles(pos, vel)
+    o.step(1, stop=STOP_DENSITY); s.step_partial(capi.STAGE_DENSITY)
+    assert rel_err(s.get("dens"), o.get("dens")) <= TOL_STAGE
+    assert rel_err(s.get("pres"), o.get("pres")) <= TOL_STAGE
+    # forces
+    s.set_particles(pos, vel)
+    o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
+    assert rel_err(s.get("forces"), o.get("forces")) <= TOL_STAGE
+    # and against the committed fixture
+    g = np.load(os.path.join(GOLD, "sesph_default.npz"))
+    np.testing.assert_array_equal(s.get("hash"), g["hash"])
+    np.testing.assert_array_equal(s.get("index"), g["index"])
+    assert rel_err(s.get("dens"), g["dens"]) <= TOL_STAGE
+    assert rel_err(s.get("forces"), g["forces"]) <= TOL_STAGE
+
+
+@pytest.mark.parametrize("ref", [False, True], ids=["tiled", "reforder"])
+def test_sesph_stages_dam_break_with_boundaries(hip_lib, ref):
+    p, sc = small_dam_break()
+    o, s = make_pair(p, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], ref=ref)
+    # updateGrid rule + boundary tables
+    np.testing.assert_array_equal(s.params.view(np.uint8), o.params.view(np.uint8))
+    np.testing.assert_array_equal(s.get("bhash"), o.get("bhash"))
+    np.testing.assert_array_equal(s.get("bindex"), o.get("bindex"))
+    check_cell_tables(s.get("bCellStart"), s.get("bCellEnd"), o.get("bCellStart"), o.get("bCellEnd"))
+    bs = s.get("bSorted")
+    np.testing.assert_array_equal(bs[:, :3], o.get("sbi")[:, :3])
+    np.testing.assert_array_equal(bs[:, 3], o.get("svbi"))
+    o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    np.testing.assert_array_equal(s.get("index"), o.get("index"))
+    check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
+    assert rel_err(s.get("dens"), o.get("dens")) <= TOL_STAGE
+    assert rel_err(s.get("pres"), o.get("pres")) <= TOL_STAGE
+    assert rel_err(s.get("forces"), o.get("forces")) <= TOL_STAGE
+
+
+@pytest.mark.parametrize("ref", [False, True], ids=["tiled", "reforder"])
+@pytest.mark.parametrize("scene_name", ["default", "dambreak"])
+def test_sesph_n_steps(hip_lib, ref, scene_name):
+    if scene_name == "default":
+        p, pos, vel = default_scene(SESPH)
+        bi = vbi = None
+        gold, steps = np.load(os.path.join(GOLD, "sesph_default.npz")), 10
+    else:
+        p, sc = small_dam_break()
+        pos, vel, bi, vbi = sc["pos"], sc["vel"], sc["bi"], sc["vbi"]
+        gold, steps = np.load(os.path.join(GOLD, "sesph_dambreak.npz")), 10
+    o, s = make_pair(p, pos, vel, bi, vbi, ref=ref)
+    o.step(steps); s.step(steps)
+    gp, gv = s.download()
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+    np.testing.assert_array_equal(gp[:, 3], o.get("pos")[:, 3])
+    assert rel_err(gp[:, :3], gold["pos%d" % steps][:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], gold["vel%d" % steps][:, :3]) <= TOL_STEPS
+    # the sorted hash / index of the last step are bit-exact too (order of the output arrays)
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    np.testing.assert_array_equal(s.get("index"), o.get("index"))
+    # 40 more steps (50 in total)
+    o.step(40); s.step(40)
+    gp, gv = s.download()
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= 5 * TOL_STEPS
+
+
+def test_tiled_equals_reference_order_bitwise(hip_lib):
+    """Two different kernels (LDS hit-list vs plain 27-cell walk) must agree bit for bit."""
+    p, sc = small_dam_break((20, 16, 14))
+    outs = []
+    for ref in (False, True):
+        s = capi.Solver(p, len(sc["pos"]), reference_order=ref)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step_partial(capi.STAGE_FORCES)
+        outs.append((s.get("dens"), s.get("pres"), s.get("forces")))
+        s.set_particles(sc["pos"], sc["vel"])
+        s.step(5)
+        outs[-1] += s.download()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_edge_cases(hip_lib):
+    p = Oracle.default_params(SESPH)
+    # empty: stepping an empty solver is a no-op
+    s = capi.Solver(p, 16)
+    s.step(2)
+    assert s.n == 0
+    # one particle: density is the self term only, it free-falls
+    one = np.array([[0.1, 0.2, 0.3, 1.0]], np.float32)
+    o, s = make_pair(p, one, np.zeros_like(one), capacity=16)
+    o.step(3); s.step(3)
+    gp, gv = s.download()
+    np.testing.assert_array_equal(gp, o.get("pos"))
+    np.testing.assert_array_equal(gv, o.get("vel"))
+    # ragged sizes around the 256-thread block, and appending particles between steps (main.cpp:499-513)
+    rng = np.random.default_rng(7)
+    for n in (255, 256, 257, 1000):
+        pos = np.ones((n, 4), np.float32)
+        pos[:, :3] = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+        vel = np.zeros_like(pos)
+        vel[:, :3] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        o, s = make_pair(p, pos, vel, capacity=2048)
+        o.step(2); s.step(2)
+        gp, gv = s.download()
+        assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+        extra = np.ones((10, 4), np.float32)
+        extra[:, :3] = rng.uniform(-0.3, 0.3, (10, 3)).astype(np.float32)
+        s.set_particles(extra, None, first=s.n)
+        o.set_particles(np.concatenate([o.get("pos"), extra]), np.concatenate([o.get("vel"), np.zeros_like(extra)]))
+        o.step(1); s.step(1)
+        assert s.n == n + 10
+        gp, gv = s.download()
+        assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+
+
+def test_crowded_cell_overflow_path_and_wrap(hip_lib):
+    """>HIT_CAP neighbours per particle (overflow → reference-order path inside the tiled kernels), particles
+    outside the grid (hash wraps by & (gridSize-1), negative cells included) and a cell at the x edge."""
+    p = Oracle.default_params(SESPH)
+    rng = np.random.default_rng(11)
+    h = float(p["interactionRadius"][0])
+    blob = np.ones((150, 4), np.float32)
+    blob[:, :3] = (np.array([0.2, 0.1, -0.3]) + rng.uniform(-0.4 * h, 0.4 * h, (150, 3))).astype(np.float32)
+    far = np.ones((40, 4), np.float32)
+    far[:, :3] = rng.uniform(-3.0, 3.0, (40, 3)).astype(np.float32)          # outside [-1.1, 1.82)
+    edge = np.ones((40, 4), np.float32)
+    edge[:, :3] = rng.uniform(-1.1, -1.1 + 2 * h, (40, 3)).astype(np.float32)  # cells 0..1 in x,y,z
+    pos = np.concatenate([blob, far, edge])
+    vel = np.zeros_like(pos)
+    for ref in (False, True):
+        o, s = make_pair(p, pos, vel, ref=ref)
+        o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+        np.testing.assert_array_equal(s.get("index"), o.get("index"))
+        check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
+        assert rel_err(s.get("dens"), o.get("dens")) <= TOL_STAGE
+        assert rel_err(s.get("forces"), o.get("forces")) <= 10 * TOL_STAGE
+
+
+def test_iisph_stages_and_steps(hip_lib):
+    p, pos, vel = compressed_block()
+    o, s = make_pair(p, pos, vel, solver=IISPH)
+    stages = [(STOP_I_DISPLACEMENT, capi.STAGE_I_DISPLACEMENT, ["dens", "velAdv", "forcesAdv", "diiFluid", "diiBoundary"]),
+              (STOP_I_ADVECTION, capi.STAGE_I_ADVECTION, ["densAdv", "aii", "P_l"]),
+              (STOP_I_SOLVE, capi.STAGE_I_SOLVE, ["sumDij", "densCorr", "P_l", "pres"]),
+              (STOP_I_PFORCE, capi.STAGE_I_PFORCE, ["forcesP"])]
+    for ostop, gstop, names in stages:
+        o.set_particles(pos, vel); s.set_particles(pos, vel)
+        o.step(1, stop=ostop); s.step_partial(gstop)
+        for nm in names:
+            assert rel_err(s.get(nm), o.get(nm)) <= 5 * TOL_STAGE, nm
+    assert s.last_iterations == o.last_iters
+    g = np.load(os.path.join(GOLD, "iisph_compressed.npz"))
+    assert rel_err(s.get("forcesP"), g["forcesP"]) <= 5 * TOL_STAGE
+    o.set_particles(pos, vel); s.set_particles(pos, vel)
+    o.step(5); s.step(5)
+    gp, gv, gpr = s.download(pressure=True)
+    assert s.last_iterations == o.last_iters == int(g["iters5"][0])
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+    assert rel_err(gpr, o.get("pressure")) <= 10 * TOL_STEPS
+    assert rel_err(gp[:, :3], g["pos5"][:, :3]) <= TOL_STEPS
+
+
+def test_iisph_with_boundaries(hip_lib):
+    p, sc = small_dam_break(solver=IISPH)
+    o, s = make_pair(p, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], solver=IISPH)
+    o.step(1, stop=STOP_I_PFORCE); s.step_partial(capi.STAGE_I_PFORCE)
+    for nm in ("dens", "diiBoundary", "aii", "densAdv", "sumDij", "densCorr", "forcesP"):
+        assert rel_err(s.get(nm), o.get(nm)) <= 5 * TOL_STAGE, nm
+    o.set_particles(sc["pos"], sc["vel"]); s.set_particles(sc["pos"], sc["vel"])
+    o.step(5); s.step(5)
+    gp, gv = s.download()
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+
+
+@pytest.mark.parametrize("double,kset", [(False, 0), (True, 1), (True, 0)], ids=["f32-monaghan", "f64-muller", "f64-monaghan"])
+def test_other_precision_and_kernel_sets(hip_lib, double, kset):
+    """DOUBLE_PRECISION / KERNEL_SET variants (config 5 = fp64 + Monaghan), incl. the float-scalar helper
+    semantics of SURVEY Q11."""
+    p, sc = small_dam_break(double=double, kernel_set=kset)
+    for ref in (False, True):
+        o, s = make_pair(p, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], double=double, kset=kset, ref=ref)
+        o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+        np.testing.assert_array_equal(s.get("index"), o.get("index"))
+        assert rel_err(s.get("dens"), o.get("dens")) <= TOL_STAGE
+        assert rel_err(s.get("forces"), o.get("forces")) <= TOL_STAGE
+        o.set_particles(sc["pos"], sc["vel"]); s.set_particles(sc["pos"], sc["vel"])
+        o.step(10); s.step(10)
+        gp, gv = s.download()
+        assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+        assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+
+
+def test_full_size_c2_properties(hip_lib):
+    """BASELINE config C2 (1,000,000 particles + tank): size-independent properties, tiled == reference-order
+    bit for bit, and the oracle on the same inputs for one full force evaluation."""
+    p = Oracle.default_params(SESPH)
+    sc = scene.dam_break("C2", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    n = len(sc["pos"])
+    assert n == 1_000_000
+    res = []
+    for ref in (False, True):
+        s = capi.Solver(p, n, reference_order=ref)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step_partial(capi.STAGE_FORCES)
+        res.append(dict(hash=s.get("hash"), index=s.get("index"), cs=s.get("cellStart"), ce=s.get("cellEnd"),
+                        dens=s.get("dens"), forces=s.get("forces"), params=s.params))
+        s.close()
+    a, b = res
+    assert np.all(np.diff(a["hash"].astype(np.int64)) >= 0)                 # sortedness
+    assert np.array_equal(np.sort(a["index"]), np.arange(n, dtype=np.uint32))  # a permutation
+    m = a["cs"] != 0xFFFFFFFF
+    assert int((a["ce"][m].astype(np.int64) - a["cs"][m]).sum()) == n        # cells tile the sorted array
+    assert np.array_equal(np.unique(a["hash"]), np.nonzero(m)[0])
+    for k in ("hash", "index", "dens", "forces"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    o = Oracle(p, solver=SESPH, threads=min(16, os.cpu_count() or 1))
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    np.testing.assert_array_equal(a["params"].view(np.uint8), o.params.view(np.uint8))
+    o.step(1, stop=STOP_FORCES)
+    np.testing.assert_array_equal(a["hash"], o.get("hash"))
+    np.testing.assert_array_equal(a["index"], o.get("index"))
+    assert rel_err(a["dens"], o.get("dens")) <= TOL_STAGE
+    assert rel_err(a["forces"], o.get("forces")) <= TOL_STAGE
+
+
+def test_params_change_and_diagnostics(hip_lib):
+    p, pos, vel = default_scene(SESPH)
+    o, s = make_pair(p, pos, vel)
+    q = p.copy()
+    q["gravity"][0][1] = 0.0        # setGravity(0.0), main.cpp:538
+    q["gridSize"][0] = (128, 64, 32)  # a re-grid: cell tables are re-allocated
+    q["numCells"][0] = 128 * 64 * 32
+    o.set_params(q); s.set_params(q)
+    o.step(3); s.step(3)
+    gp, gv = s.download()
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    assert abs(s.max_density() - float(o.get("dens").max())) <= 1e-3
+    assert abs(s.max_velocity() - float(np.linalg.norm(o.get("vel")[:, :3].astype(np.float64), axis=1).max())) <= 1e-5
