@@ -35,7 +35,9 @@ template <typename R> NRS_DEV V3<R> operator*(V3<R> a, float b) { return mk3<R>(
 template <typename R> NRS_DEV V3<R> operator*(float b, V3<R> a) { return mk3<R>(b * a.x, b * a.y, b * a.z); }
 template <typename R> NRS_DEV V3<R> operator/(V3<R> a, float b) { return mk3<R>(a.x / b, a.y / b, a.z / b); }
 template <typename R> NRS_DEV float dot(V3<R> a, V3<R> b) { return (float)(a.x * b.x + a.y * b.y + a.z * b.z); }
-NRS_DEV float sqrt_rn(float x) { return __fsqrt_rn(x); }
+// NB: __fsqrt_rn is the NATIVE (1-ulp) sqrt in this HIP; sqrtf is the correctly rounded one (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+NRS_DEV float sqrt_rn(float x) { return sqrtf(x); }
 template <typename R> NRS_DEV float length(V3<R> v) { return sqrt_rn(dot(v, v)); }
 
 // x^3 the way g++ evaluates pow(SReal,int): in double, rounded once to SReal (kernels_impl.cuh:95)
