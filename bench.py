@@ -42,13 +42,33 @@ def sesph_bytes_per_particle_step(num_cells, real_bytes=4):
     return base + 16 * passes, passes
 
 
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes 256 logical CPUs in the mask but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return int(os.environ.get("NEREUS_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(seconds_target=15.0):
     """Time the CPU oracle (restatement of the reference algorithm, OpenMP over particles) on the C1 scene:
     the same generator and parameters as the GPU workload at 32^3 = 32,768 particles."""
     from nereus_amd import scene
     from tests.oracle_lib import SESPH, Oracle
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     p = Oracle.default_params(SESPH)
     sc = scene.dam_break("C1", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
     o = Oracle(p, solver=SESPH, threads=cores)
