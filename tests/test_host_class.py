@@ -1,0 +1,106 @@
+"""The C++ host mirror (Nereus::SPH / Nereus::IISPH in nereus_amd/host) driven through its class API by the
+headless driver — what main.cpp does without the viewer."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from nereus_amd.params import params_dtype
+from tests.common import compressed_block, default_scene, rel_err, small_dam_break
+from tests.oracle_lib import IISPH, SESPH, Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "nereus_amd", "nereus_headless")
+
+
+def _driver():
+    if not os.path.exists(DRIVER):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "nereus_amd", "host")])
+    return DRIVER
+
+
+def _read_out(path):
+    raw = open(path, "rb").read()
+    n, nb, iters, ps = struct.unpack_from("<4I", raw, 0)
+    off = 16
+    p = np.frombuffer(raw, dtype=params_dtype(False), count=1, offset=off).copy()
+    off += ps
+    def take(count, cols):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=np.float32, count=count * cols, offset=off).copy()
+        off += 4 * count * cols
+        return a.reshape(count, cols) if cols > 1 else a
+    out = dict(n=n, nb=nb, iters=iters, params=p, pos=take(n, 4), vel=take(n, 4), pressure=take(n, 1))
+    if nb:
+        out["bi"] = take(nb, 4)
+        out["vbi"] = take(nb, 1)
+    return out
+
+
+def _write_in(path, pos, vel, bi, vbi):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2I", len(pos), 0 if bi is None else len(bi)))
+        f.write(np.ascontiguousarray(pos, np.float32).tobytes())
+        f.write(np.ascontiguousarray(vel, np.float32).tobytes())
+        if bi is not None and len(bi):
+            f.write(np.ascontiguousarray(bi, np.float32).tobytes())
+            f.write(np.ascontiguousarray(vbi, np.float32).tobytes())
+
+
+@pytest.mark.parametrize("kind,solver", [("sesph", SESPH), ("iisph", IISPH)])
+def test_constructor_defaults_match_oracle(tmp_path, kind, solver):
+    """No GPU needed: constructing the solver and reading its parameters never touches the device."""
+    out = str(tmp_path / "p.bin")
+    subprocess.check_call([_driver(), "params", kind, out], stdout=subprocess.DEVNULL)
+    got = _read_out(out)["params"]
+    want = Oracle.default_params(solver)
+    for name in want.dtype.names:
+        np.testing.assert_array_equal(got[name], want[name], err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,solver", [("sesph", SESPH), ("iisph", IISPH)])
+def test_class_api_run_matches_oracle(tmp_path, hip_lib, kind, solver):
+    if solver == SESPH:
+        p, sc = small_dam_break()
+        pos, vel, bi, vbi = sc["pos"], sc["vel"], sc["bi"], sc["vbi"]
+    else:
+        p, pos, vel = compressed_block()
+        bi = vbi = None
+    steps = 6
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_in(fin, pos, vel, bi, vbi)
+    subprocess.check_call([_driver(), "run", kind, fin, str(steps), fout], stdout=subprocess.DEVNULL)
+    got = _read_out(fout)
+    o = Oracle(p, solver=solver)
+    o.set_particles(pos, vel)
+    o.set_boundaries(bi, vbi, update_grid=True)
+    o.step(steps)
+    np.testing.assert_array_equal(got["params"].view(np.uint8), o.params.view(np.uint8))
+    assert rel_err(got["pos"][:, :3], o.get("pos")[:, :3]) <= 1e-5
+    assert rel_err(got["vel"][:, :3], o.get("vel")[:, :3]) <= 1e-5
+    if solver == IISPH:
+        assert got["iters"] == o.last_iters
+        assert rel_err(got["pressure"], o.get("pressure")) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_main_cpp_scene_through_class_api(tmp_path, hip_lib):
+    """main.cpp:533-553 — IISPH(), generateParticleCube, sampleBox/getVbi, updateGpuBoundaries, update()."""
+    fout = str(tmp_path / "out.bin")
+    env = dict(os.environ, NEREUS_MAIN_GRAVITY_OFF="1")
+    subprocess.check_call([_driver(), "mainscene", "iisph", "3", fout], stdout=subprocess.DEVNULL, env=env)
+    got = _read_out(fout)
+    assert got["n"] == 1331 and got["nb"] > 100000
+    p, pos, vel = default_scene(IISPH)
+    p["gravity"][0][1] = 0.0
+    o = Oracle(p, solver=IISPH)
+    o.set_particles(pos, vel)
+    o.set_boundaries(got["bi"], got["vbi"], update_grid=True)
+    o.step(3)
+    np.testing.assert_array_equal(got["params"].view(np.uint8), o.params.view(np.uint8))
+    assert got["iters"] == o.last_iters
+    assert rel_err(got["pos"][:, :3], o.get("pos")[:, :3]) <= 1e-5
+    assert rel_err(got["vel"][:, :3], o.get("vel")[:, :3]) <= 1e-5
