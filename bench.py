@@ -123,8 +123,12 @@ def main():
 
     lattice = scene.CONFIGS[args.config] if args.config in scene.CONFIGS else tuple(int(v) for v in args.config.split(","))
 
-    if world > 1:
+    if world > 1 or os.environ.get("NEREUS_BENCH_FORCE_SLAB"):
         from nereus_amd import slab
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
         result = slab.bench_main(args, lattice, rank, world, local_rank)
         if rank == 0:

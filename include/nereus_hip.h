@@ -210,6 +210,26 @@ int nrs_set_max_iterations(nrs_ctx *ctx, uint32_t max_iters);
 int nrs_set_profiling(nrs_ctx *ctx, uint32_t stage_mask);
 int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches);
 
+/* ---- multi-GPU slab decomposition (new; the reference is single-GPU — SURVEY §8e) ---------------------------
+ * One context per rank/GPU.  A rank owns the particles whose GLOBAL grid cell-x index (floor((x-origin.x)/cell.x),
+ * same SphSimParams on every rank) lies in [cell_lo, cell_hi).  Per step, before nrs_step:
+ *   nrs_slab_pack   partitions the current particles (stable, deterministic): owned ones are compacted, leavers and
+ *                   the halo_cells-wide border layers are written to the two caller-owned DEVICE message buffers;
+ *   (caller)        exchanges the buffers with the left/right neighbour — RCCL send/recv over xGMI, e.g.
+ *                   torch.distributed.batch_isend_irecv on the tensors that own the buffers;
+ *   nrs_slab_unpack appends the received migrants (they become owned) and halo copies (read-only, pos.w = 2).
+ * nrs_step then evaluates density on owned particles plus one cell beyond each cut and forces on owned particles
+ * only.  Message buffer: nrs_slab_message_bytes(capacity, precision) bytes =
+ *   [u32 nMigrants, u32 nHalo, u32 0, u32 0 | vec4 pos[capacity] | vec4 vel[capacity]].
+ * Pass NULL for the neighbour that does not exist (ends of the chain).  SESPH only in this version. */
+int nrs_slab_configure(nrs_ctx *ctx, int32_t cell_lo, int32_t cell_hi, int32_t halo_cells);
+/* counts (optional) receives {stay, migrate-left, halo-left, migrate-right, halo-right, ghost}. */
+int nrs_slab_pack(nrs_ctx *ctx, void *send_left, void *send_right, uint64_t capacity, uint32_t counts[6]);
+int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right, uint64_t capacity);
+/* owned particles (the first nrs_num_owned() entries of NRS_ARR_POS/VEL right after nrs_slab_pack/unpack) */
+uint64_t nrs_num_owned(nrs_ctx *ctx);
+uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision);
+
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);
 int nrs_max_velocity(nrs_ctx *ctx, double *out_speed);

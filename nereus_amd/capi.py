@@ -42,7 +42,8 @@ EXPORTS = [
     "nrs_get_params", "nrs_upload_particles", "nrs_set_num_particles", "nrs_num_particles", "nrs_set_boundaries",
     "nrs_step", "nrs_step_partial", "nrs_synchronize", "nrs_download", "nrs_get_array", "nrs_device_ptr",
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
-    "nrs_max_velocity",
+    "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
+    "nrs_slab_message_bytes",
 ]
 
 
@@ -97,6 +98,13 @@ def load_library(path=None):
     lib.nrs_stage_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     lib.nrs_max_density.argtypes = [vp, C.POINTER(C.c_double)]
     lib.nrs_max_velocity.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.nrs_slab_configure.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.nrs_slab_pack.argtypes = [vp, vp, vp, u64, C.POINTER(C.c_uint32)]
+    lib.nrs_slab_unpack.argtypes = [vp, vp, vp, u64]
+    lib.nrs_num_owned.argtypes = [vp]
+    lib.nrs_num_owned.restype = u64
+    lib.nrs_slab_message_bytes.argtypes = [u64, i32]
+    lib.nrs_slab_message_bytes.restype = u64
     _lib = lib
     return lib
 
@@ -240,6 +248,25 @@ class Solver:
             if cnt.value:
                 out[name] = (ms.value, cnt.value)
         return out
+
+    # ---- slab decomposition ------------------------------------------------------------------------
+    def slab_configure(self, cell_lo, cell_hi, halo_cells=2):
+        self._chk(self.lib.nrs_slab_configure(self.h, int(cell_lo), int(cell_hi), int(halo_cells)))
+
+    def slab_pack(self, send_left_ptr, send_right_ptr, capacity):
+        counts = (C.c_uint32 * 6)()
+        self._chk(self.lib.nrs_slab_pack(self.h, send_left_ptr, send_right_ptr, int(capacity), counts))
+        return list(counts)
+
+    def slab_unpack(self, recv_left_ptr, recv_right_ptr, capacity):
+        self._chk(self.lib.nrs_slab_unpack(self.h, recv_left_ptr, recv_right_ptr, int(capacity)))
+
+    @property
+    def n_owned(self):
+        return int(self.lib.nrs_num_owned(self.h))
+
+    def message_bytes(self, capacity):
+        return int(self.lib.nrs_slab_message_bytes(int(capacity), 64 if self.double else 32))
 
     def max_density(self):
         v = C.c_double()

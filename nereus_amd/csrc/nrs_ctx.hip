@@ -17,6 +17,8 @@
 #include "../../include/nereus_hip.h"
 #include "nrs_kernels_ref.h"
 #include "nrs_kernels_tiled.h"
+#include "nrs_kernels_slab.h"
+#include <climits>
 
 namespace nrs {
 
@@ -85,6 +87,10 @@ struct CtxBase {
     virtual int array(int which, void **dptr, uint64_t *bytes) = 0;
     virtual int stage_ms(int stage, float *ms, uint32_t *launches) = 0;
     virtual int reduce_max(int which, double *out) = 0;
+    virtual int slab_configure(int lo, int hi, int halo) = 0;
+    virtual int slab_pack(void *sendL, void *sendR, uint64_t cap, uint32_t *counts) = 0;
+    virtual int slab_unpack(const void *recvL, const void *recvR, uint64_t cap) = 0;
+    virtual uint64_t num_owned() = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int device = 0;
@@ -110,6 +116,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     // IISPH
     DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij;
     DevBuf redPartial, redOut;
+    // slab decomposition
+    bool slabOn = false;
+    SlabCfg slab = {INT_MIN / 2, INT_MAX / 2, 2};
+    DevBuf ghostPos, ghostVel, slabCounts, slabTotals;
+    uint64_t nOwned = 0;
+    uint32_t ghostCount = 0;
+    bool cellsClean = false; // cellStart is all-EMPTY
     // profiling
     struct Ev { int stage; hipEvent_t a, b; };
     std::vector<Ev> evPool;
@@ -134,7 +147,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &redPartial, &redOut};
+                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &ghostPos, &ghostVel, &slabCounts, &slabTotals};
         for (DevBuf *b : all) b->release();
         if (ownStream && stream) (void)hipStreamDestroy(stream);
     }
@@ -150,6 +163,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(bCellEnd.alloc(C * 4));
         }
         if (cellsAllocated != C) {
+            cellsClean = false;
             HIPCHK(hipMemsetAsync(cellEnd.p, 0, C * 4, stream));
             if (nb) HIPCHK(hipMemsetAsync(bCellEnd.p, 0, C * 4, stream));
             cellsAllocated = (uint32_t)C;
@@ -359,6 +373,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         G.cellStart = cellStart.as<uint32_t>(); G.cellEnd = cellEnd.as<uint32_t>();
         G.bCellStart = bCellStart.as<uint32_t>(); G.bCellEnd = bCellEnd.as<uint32_t>();
         G.sB = bSorted.as<T4>();
+        G.actLo = INT_MIN;
+        G.actHi = INT_MAX;
         return G;
     }
     IisphArrays<R> iisph_view() const
@@ -393,7 +409,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (stop == NRS_STAGE_SORT) return NRS_OK;
 
         NRSCHK(ev_begin(NRS_STAGE_REORDER));
-        HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
+        if (!cellsClean) HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
+        cellsClean = false;
         hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                            iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                            cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
@@ -405,12 +422,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         const uint32_t N = (uint32_t)n;
         const dim3 g(nblocks(N)), b(BLOCK);
-        const GridView<R> G = grid_view();
+        GridView<R> G = grid_view();
+        if (slabOn) { G.actLo = slab.lo - 1; G.actHi = slab.hi + 1; } // density is also needed one cell beyond the cuts
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         if (refOrder())
             hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         else
             launch_density_tiled<R, KSET, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        if (slabOn) { G.actLo = slab.lo; G.actHi = slab.hi; }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_DENSITY) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_FORCES));
@@ -508,6 +527,96 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    // ---- slab decomposition (nrs_kernels_slab.h) -------------------------------------------------------
+    int slab_configure(int lo, int hi, int halo) override
+    {
+        if (iisph()) return fail(NRS_E_STATE, "slab decomposition is implemented for the SESPH solver only");
+        if (halo < 2) return fail(NRS_E_INVALID, "halo must be >= 2 cells (one cell for the density of the ring + one)");
+        if ((long long)hi - lo < 2ll * halo) return fail(NRS_E_INVALID, "slab narrower than two halos");
+        slab.lo = lo; slab.hi = hi; slab.halo = halo;
+        slabOn = true;
+        nOwned = n;
+        return NRS_OK;
+    }
+    uint64_t num_owned() override { return slabOn ? nOwned : n; }
+
+    int slab_pack(void *sendL, void *sendR, uint64_t cap, uint32_t *counts) override
+    {
+        if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
+        if (midStep) return fail(NRS_E_STATE, "state is mid-update");
+        if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
+        const uint32_t N = (uint32_t)n;
+        const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_BLOCK - 1) / SLAB_BLOCK);
+        NRSCHK(slabCounts.alloc((size_t)ST_COUNT * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
+        NRSCHK(slabTotals.alloc(ST_COUNT * 4));
+        NRSCHK(ghostPos.alloc(sizeof(T4) * cap));
+        NRSCHK(ghostVel.alloc(sizeof(T4) * cap));
+        uint32_t tot[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+        if (N) {
+            hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
+                               slabCounts.as<uint32_t>(), nbk);
+            hipLaunchKernelGGL(k_slab_scan, dim3(ST_COUNT), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
+                               slabTotals.as<uint32_t>());
+            SlabOut<R> out;
+            out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
+            out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
+            out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
+            out.cap = (uint32_t)cap;
+            hipLaunchKernelGGL((k_slab_scatter<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
+                               slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+            hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
+                               (unsigned char *)sendR);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(tot, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        } else {
+            HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_COUNT * 4, stream));
+            hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
+                               (unsigned char *)sendR);
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        if ((uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > cap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > cap || tot[ST_GHOST] > cap)
+            return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
+        if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
+        n = tot[ST_STAY];
+        nOwned = n;
+        ghostCount = tot[ST_GHOST];
+        if (counts) std::memcpy(counts, tot, sizeof(tot));
+        return NRS_OK;
+    }
+    uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_BLOCK - 1) / SLAB_BLOCK); }
+
+    int slab_unpack(const void *recvL, const void *recvR, uint64_t mcap) override
+    {
+        if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
+        uint32_t hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
+        if (recvL) HIPCHK(hipMemcpyAsync(hL, recvL, 16, hipMemcpyDeviceToHost, stream));
+        if (recvR) HIPCHK(hipMemcpyAsync(hR, recvR, 16, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if ((uint64_t)hL[0] + hL[1] > mcap || (uint64_t)hR[0] + hR[1] > mcap) return fail(NRS_E_INVALID, "corrupt slab message header");
+        const uint64_t total = n + hL[0] + hR[0] + ghostCount + hL[1] + hR[1];
+        if (total > cap) return fail(NRS_E_CAPACITY, "owned + halo particles exceed the context capacity");
+        const unsigned char *bL = (const unsigned char *)recvL, *bR = (const unsigned char *)recvR;
+        auto mp = [&](const unsigned char *b) { return (const T4 *)(b + 16); };
+        auto mv = [&](const unsigned char *b) { return (const T4 *)(b + 16 + (size_t)mcap * sizeof(T4)); };
+        AppendPieces<R> A;
+        const uint32_t len[5] = {hL[0], hR[0], ghostCount, hL[1], hR[1]};
+        A.srcPos[0] = bL ? mp(bL) : nullptr;           A.srcVel[0] = bL ? mv(bL) : nullptr;            // migrants from the left
+        A.srcPos[1] = bR ? mp(bR) : nullptr;           A.srcVel[1] = bR ? mv(bR) : nullptr;            // migrants from the right
+        A.srcPos[2] = ghostPos.as<T4>();               A.srcVel[2] = ghostVel.as<T4>();               // our ghosts
+        A.srcPos[3] = bL ? mp(bL) + hL[0] : nullptr;   A.srcVel[3] = bL ? mv(bL) + hL[0] : nullptr;    // halo from the left
+        A.srcPos[4] = bR ? mp(bR) + hR[0] : nullptr;   A.srcVel[4] = bR ? mv(bR) + hR[0] : nullptr;    // halo from the right
+        A.start[0] = 0;
+        for (int k = 0; k < 5; ++k) A.start[k + 1] = A.start[k] + len[k];
+        if (A.start[5])
+            hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, A,
+                               posA.as<T4>(), velA.as<T4>(), (uint32_t)n);
+        HIPCHK(hipGetLastError());
+        nOwned = n + hL[0] + hR[0];
+        n = total;
+        return NRS_OK;
+    }
+
     int step(int nsteps, int stop) override
     {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
@@ -520,6 +629,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             else { if (nb) NRSCHK(sesph_tail<true>(stop)); else NRSCHK(sesph_tail<false>(stop)); }
             HIPCHK(hipGetLastError());
             if (stop) { midStep = true; break; }
+            if ((uint64_t)P.numCells > 8ull * n) { // big, mostly empty table: undo only the touched cells
+                hipLaunchKernelGGL(k_clear_cells, dim3(nblocks(n)), dim3(BLOCK), 0, stream, hashCur, cellStart.as<uint32_t>(), (uint32_t)n);
+                cellsClean = true;
+            }
             // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
             std::swap(posA.p, posB.p);
             std::swap(velA.p, velB.p);
@@ -753,6 +866,24 @@ int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches)
     if (!ms) return fail(NRS_E_INVALID, "NULL argument");
     return ctx->impl->stage_ms(stage, ms, launches);
 }
+int nrs_slab_configure(nrs_ctx *ctx, int32_t cell_lo, int32_t cell_hi, int32_t halo_cells)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->slab_configure(cell_lo, cell_hi, halo_cells);
+}
+int nrs_slab_pack(nrs_ctx *ctx, void *send_left, void *send_right, uint64_t capacity, uint32_t counts[6])
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->slab_pack(send_left, send_right, capacity, counts);
+}
+int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right, uint64_t capacity)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->slab_unpack(recv_left, recv_right, capacity);
+}
+uint64_t nrs_num_owned(nrs_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->num_owned() : 0; }
+uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision) { return 16 + capacity * 2 * (precision == 64 ? 32 : 16); }
+
 int nrs_max_density(nrs_ctx *ctx, double *out)
 {
     CTX_GUARD(ctx);

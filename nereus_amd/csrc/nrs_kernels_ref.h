@@ -18,7 +18,16 @@ template <typename R> struct GridView {
     const uint32_t *cellStart, *cellEnd;   // fluid cell table
     const uint32_t *bCellStart, *bCellEnd; // boundary cell table (valid only when the kernel has HAS_B)
     const T4 *sB;                          // sorted boundary particles: xyz + Vbi in w
+    // slab decomposition: a gather kernel evaluates only particles whose (unwrapped) cell-x is in [actLo, actHi)
+    // and writes zeros for the rest (halo copies whose neighbourhood is incomplete on this rank)
+    int actLo, actHi;
 };
+
+template <typename R> NRS_DEV bool slab_active(const Params<R> &P, const GridView<R> &G, R x)
+{
+    const long long cx = (long long)floor((x - P.worldOrigin[0]) / P.cellSize[0]);
+    return cx >= (long long)G.actLo && cx < (long long)G.actHi;
+}
 
 constexpr int BLOCK = 256;
 
@@ -61,6 +70,17 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
     sVel[i] = oldVel[src];
     if (oldPres) sPres[i] = oldPres[src];
     if (inv) inv[src] = i;
+}
+
+// Undo of the cell table after a step: reset cellStart of exactly the cells the step filled (replaces the
+// reference's per-step cudaMemset of 4*numCells bytes, sph_cuda.cu:318, whose cost grows with the EMPTY volume)
+__global__ __launch_bounds__(BLOCK) void k_clear_cells(const uint32_t *__restrict__ hash, uint32_t *__restrict__ cellStart,
+                                                       uint32_t n)
+{
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = hash[i];
+    if (i == 0 || h != hash[i - 1]) cellStart[h] = CELL_EMPTY;
 }
 
 // boundary flavour (sph_kernel_impl.cuh:150-205, intended semantics — SURVEY Q1): sorted xyz + vbi packed in one vec4
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_density_ref(Params<R> P, GridView<R> 
 {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (!slab_active<R>(P, G, sPos[i].x)) { dens[i] = (R)0; if (pres) pres[i] = (R)0; return; }
     const R d = density_of<R, KSET, HAS_B>(P, G, sPos, i);
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
@@ -285,6 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_forces_ref(Params<R> P, GridView<R> G
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const V3<R> pos = xyz<R>(sPos[i]);
+    if (!slab_active<R>(P, G, pos.x)) { forces[i] = mk4<R>((R)0, (R)0, (R)0, (R)0); return; }
     const V3<R> vel = xyz<R>(sVel[i]);
     const R dens = sDens[i], pres = sPres[i];
     ForceAcc<R> A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos, vel, dens, pres, sPos, sVel, sDens, sPres);

@@ -1,0 +1,189 @@
+// nrs_kernels_slab.h — device side of the multi-GPU slab decomposition (new: the reference is
+// single-GPU).  Each rank owns the particles whose global grid cell-x lies in [lo, hi).  Once per step, before
+// update(), every rank partitions its current particles into six streams with ONE stable multi-way
+// compaction (count → scan → scatter; deterministic, no atomics on the output order):
+//
+//   STAY    cell-x in [lo,hi)                      → stays owned (compacted to the front of the local arrays)
+//   MIG_L/R cell-x < lo / >= hi                    → ownership moves to the left / right neighbour
+//   HALO_L/R STAY particles within `halo` cells of the left / right cut → copied to that neighbour as read-only halo
+//   GHOST   migrants still within `halo` cells of our cut → we keep a read-only copy (they are the neighbour's now)
+//
+// Halo/ghost copies carry pos.w = 2 (owned particles have w = 1, as the reference sets it, sph/sph.cpp:381):
+// that is how they are recognised and dropped by the next partition, after the sort has interleaved them with
+// owned particles.  With a halo of two cells the density of every particle within one cell of a cut is complete
+// locally, so the force on every OWNED particle is exact without a second message per step.
+//
+// Message buffer per direction (device memory owned by the caller, e.g. a torch tensor sent with RCCL):
+//   [ u32 nMigrants, u32 nHalo, u32 0, u32 0 | vec4 pos[cap] | vec4 vel[cap] ]   migrants first, then halo.
+#pragma once
+#include "nrs_math.h"
+
+namespace nrs {
+
+enum { ST_STAY = 0, ST_MIG_L = 1, ST_HALO_L = 2, ST_MIG_R = 3, ST_HALO_R = 4, ST_GHOST = 5, ST_COUNT = 6 };
+constexpr int SLAB_BLOCK = 256;
+
+struct SlabCfg { int lo, hi, halo; };
+
+template <typename R> NRS_DEV uint32_t slab_flags(const Params<R> &P, const SlabCfg c, const typename Vec4T<R>::type q)
+{
+    if (!(q.w == (R)1)) return 0u; // last step's halo / ghost copies are dropped here
+    const long long cx = (long long)floor((q.x - P.worldOrigin[0]) / P.cellSize[0]);
+    uint32_t f = 0;
+    if (cx < c.lo) {
+        f = 1u << ST_MIG_L;
+        if (cx >= (long long)c.lo - c.halo) f |= 1u << ST_GHOST;
+    } else if (cx >= c.hi) {
+        f = 1u << ST_MIG_R;
+        if (cx < (long long)c.hi + c.halo) f |= 1u << ST_GHOST;
+    } else {
+        f = 1u << ST_STAY;
+        if (cx < (long long)c.lo + c.halo) f |= 1u << ST_HALO_L;
+        if (cx >= (long long)c.hi - c.halo) f |= 1u << ST_HALO_R;
+    }
+    return f;
+}
+
+// pass 1: per-block population of every stream
+template <typename R>
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
+                                                          uint32_t n, uint32_t *__restrict__ blockCounts, uint32_t nBlocks)
+{
+    __shared__ uint32_t cnt[ST_COUNT];
+    if (threadIdx.x < ST_COUNT) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    const uint32_t f = i < n ? slab_flags<R>(P, c, pos[i]) : 0u;
+    for (int s = 0; s < ST_COUNT; ++s) {
+        const unsigned long long m = __ballot((f >> s) & 1u);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[s], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < ST_COUNT) blockCounts[threadIdx.x * nBlocks + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// pass 2: exclusive scan of the block counts, one workgroup per stream; totals[s] = stream population
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scan(uint32_t *__restrict__ blockCounts, uint32_t nBlocks,
+                                                          uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t sm[SLAB_BLOCK];
+    __shared__ uint32_t carry;
+    uint32_t *row = blockCounts + (size_t)blockIdx.x * nBlocks;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nBlocks; base += SLAB_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nBlocks ? row[i] : 0u;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < SLAB_BLOCK; off <<= 1) { // Hillis-Steele inclusive scan
+            const uint32_t t = threadIdx.x >= (uint32_t)off ? sm[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = sm[threadIdx.x];
+        if (i < nBlocks) row[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == SLAB_BLOCK - 1) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+template <typename R> struct SlabOut {
+    typedef typename Vec4T<R>::type T4;
+    T4 *stayPos, *stayVel;   // compacted owned particles
+    T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
+    unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
+    uint32_t cap;            // particles per message buffer
+};
+
+template <typename R> NRS_DEV typename Vec4T<R>::type *msg_pos(unsigned char *buf) { return (typename Vec4T<R>::type *)(buf + 16); }
+template <typename R> NRS_DEV typename Vec4T<R>::type *msg_vel(unsigned char *buf, uint32_t cap)
+{
+    return (typename Vec4T<R>::type *)(buf + 16 + (size_t)cap * sizeof(typename Vec4T<R>::type));
+}
+
+// pass 3: stable scatter of every stream
+template <typename R>
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
+                                                            const typename Vec4T<R>::type *__restrict__ vel, uint32_t n,
+                                                            const uint32_t *__restrict__ blockOffsets, uint32_t nBlocks,
+                                                            const uint32_t *__restrict__ totals, SlabOut<R> out)
+{
+    typedef typename Vec4T<R>::type T4;
+    __shared__ uint32_t waveCnt[ST_COUNT][SLAB_BLOCK / 64];
+    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T4 p, v;
+    uint32_t f = 0;
+    if (i < n) { p = pos[i]; v = vel[i]; f = slab_flags<R>(P, c, p); }
+    uint32_t rankInWave[ST_COUNT];
+    for (int s = 0; s < ST_COUNT; ++s) {
+        const unsigned long long m = __ballot((f >> s) & 1u);
+        rankInWave[s] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) waveCnt[s][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (!f) return;
+    T4 tagged = p;
+    tagged.w = (R)2; // read-only copy
+    for (int s = 0; s < ST_COUNT; ++s) {
+        if (!((f >> s) & 1u)) continue;
+        uint32_t idx = blockOffsets[(size_t)s * nBlocks + blockIdx.x] + rankInWave[s];
+        for (uint32_t w = 0; w < wave; ++w) idx += waveCnt[s][w];
+        switch (s) {
+        case ST_STAY: out.stayPos[idx] = p; out.stayVel[idx] = v; break;
+        case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
+        case ST_MIG_L:
+            if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = p; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
+            break;
+        case ST_HALO_L:
+            idx += totals[ST_MIG_L];
+            if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = tagged; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
+            break;
+        case ST_MIG_R:
+            if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = p; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
+            break;
+        case ST_HALO_R:
+            idx += totals[ST_MIG_R];
+            if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = tagged; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
+            break;
+        }
+    }
+}
+
+__global__ void k_slab_headers(const uint32_t *__restrict__ totals, unsigned char *sendL, unsigned char *sendR)
+{
+    if (threadIdx.x == 0 && sendL) {
+        uint32_t *h = (uint32_t *)sendL;
+        h[0] = totals[ST_MIG_L]; h[1] = totals[ST_HALO_L]; h[2] = 0; h[3] = 0;
+    }
+    if (threadIdx.x == 1 && sendR) {
+        uint32_t *h = (uint32_t *)sendR;
+        h[0] = totals[ST_MIG_R]; h[1] = totals[ST_HALO_R]; h[2] = 0; h[3] = 0;
+    }
+}
+
+// append up to five (source, count) pieces behind the compacted owned particles
+template <typename R> struct AppendPieces {
+    typedef typename Vec4T<R>::type T4;
+    const T4 *srcPos[5];
+    const T4 *srcVel[5];
+    uint32_t start[6]; // exclusive prefix of the piece lengths; start[5] = total
+};
+template <typename R>
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
+                                                           typename Vec4T<R>::type *__restrict__ dstVel, uint32_t dstBase)
+{
+    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (i >= A.start[5]) return;
+    int k = 0;
+    while (k < 4 && i >= A.start[k + 1]) ++k;
+    const uint32_t j = i - A.start[k];
+    dstPos[dstBase + i] = A.srcPos[k][j];
+    dstVel[dstBase + i] = A.srcVel[k][j];
+}
+
+} // namespace nrs

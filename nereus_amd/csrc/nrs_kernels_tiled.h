@@ -136,6 +136,7 @@ __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R
     if (i >= n) return;
     const uint32_t tid = threadIdx.x;
     const V3<R> p = xyz<R>(sPos[i]);
+    if (!slab_active<R>(P, G, p.x)) { dens[i] = (R)0; if (pres) pres[i] = (R)0; return; }
     const int cnt = Sweep<R>::template scan<HAS_B, 0>(P, G, thr, sPos, i, p, lst);
     R d;
     if (cnt < 0) {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R>
     if (i >= n) return;
     const uint32_t tid = threadIdx.x;
     const V3<R> pos1 = xyz<R>(sPos[i]);
+    if (!slab_active<R>(P, G, pos1.x)) { forces[i] = mk4<R>((R)0, (R)0, (R)0, (R)0); return; }
     const V3<R> vel1 = xyz<R>(sVel[i]);
     const R dens = sDens[i], pres = sPres[i];
     const int cnt = Sweep<R>::template scan<HAS_B, (KSET == KS_MULLER ? 1 : 2)>(P, G, thr, sPos, i, pos1, lst);

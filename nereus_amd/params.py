@@ -115,3 +115,23 @@ def default_params(solver: int = 0, double: bool = False) -> np.ndarray:
     p["cellSize"][0] = (ir, ir, ir)
     p["numCells"][0] = grid ** 3
     return kernel_constants(p, 0 if solver == 0 else 1)
+
+
+def update_grid(p: np.ndarray, bbmin, bbmax) -> np.ndarray:
+    """SPH::updateGrid (sph/sph.cpp:313-337) applied to a known boundary AABB: origin = min - 0.1,
+    gridSize = nextPow2(ceil((extent + 0.1) / h)) per axis.  Used by the slab driver so that every rank has the
+    same GLOBAL grid without seeing all boundary particles."""
+    R = p.dtype["kpoly"].type
+    h = np.float64(p["interactionRadius"][0])
+    grid = []
+    for a in range(3):
+        lo, hi = R(bbmin[a]), R(bbmax[a])
+        p["worldOrigin"][0][a] = R(np.float64(lo) - 0.1)
+        size = int(np.ceil((np.float64(R(hi - lo)) + 0.1) / h))
+        v = max(size, 1) - 1
+        for s in (1, 2, 4, 8, 16):
+            v |= v >> s
+        grid.append(v + 1)
+    p["gridSize"][0] = grid
+    p["numCells"][0] = grid[0] * grid[1] * grid[2]
+    return p

@@ -80,18 +80,22 @@ def tank_extent(nx, ny, nz, h, spacing=0.02, real=np.float32):
     return tx, ty, tz
 
 
-def boundary_box(tx, ty, tz, spacing=0.02):
-    """Integer lattice coordinates (m,3) of the 5-face open box [0,tx]x[0,ty]x[0,tz] (top y=ty open)."""
-    i = np.arange(0, tx + 1, dtype=np.int64)
+def boundary_box(tx, ty, tz, spacing=0.02, i_range=None):
+    """Integer lattice coordinates (m,3) of the 5-face open box [0,tx]x[0,ty]x[0,tz] (top y=ty open).
+    i_range=(lo,hi) keeps only lattice columns lo <= i <= hi (a rank's share of a long tank)."""
+    ilo, ihi = (0, tx) if i_range is None else (max(0, i_range[0]), min(tx, i_range[1]))
+    i = np.arange(ilo, ihi + 1, dtype=np.int64)
     j = np.arange(1, ty + 1, dtype=np.int64)
     k = np.arange(0, tz + 1, dtype=np.int64)
     parts = []
     a, b = np.meshgrid(i, k, indexing="ij")  # floor y=0
     parts.append(np.stack([a.ravel(), np.zeros(a.size, np.int64), b.ravel()], 1))
     a, b = np.meshgrid(j, k, indexing="ij")  # walls x=0, x=tx
-    parts.append(np.stack([np.zeros(a.size, np.int64), a.ravel(), b.ravel()], 1))
-    parts.append(np.stack([np.full(a.size, tx, np.int64), a.ravel(), b.ravel()], 1))
-    ii = np.arange(1, tx, dtype=np.int64)
+    if ilo == 0:
+        parts.append(np.stack([np.zeros(a.size, np.int64), a.ravel(), b.ravel()], 1))
+    if ihi == tx:
+        parts.append(np.stack([np.full(a.size, tx, np.int64), a.ravel(), b.ravel()], 1))
+    ii = np.arange(max(1, ilo), min(tx - 1, ihi) + 1, dtype=np.int64)
     a, b = np.meshgrid(ii, j, indexing="ij")  # walls z=0, z=tz
     parts.append(np.stack([a.ravel(), b.ravel(), np.zeros(a.size, np.int64)], 1))
     parts.append(np.stack([a.ravel(), b.ravel(), np.full(a.size, tz, np.int64)], 1))

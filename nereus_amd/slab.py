@@ -1,0 +1,298 @@
+"""Multi-GPU slab decomposition driver: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI) for the neighbour exchange, libnereus_hip for everything that touches particles.
+
+The reference is single-GPU (no NCCL/MPI/streams anywhere); this layer is new.  Protocol per
+step (see csrc/nrs_kernels_slab.h for the device side):
+
+    engine.pack(sendL, sendR)        partition current particles; fill the two message buffers
+    isend/irecv with rank-1, rank+1  ONE fixed-size message per direction (migrants + 2-cell halo)
+    engine.unpack(recvL, recvR)      append migrants (owned) and halo copies (read-only)
+    engine.step()                    update(): density on owned + 1 cell, forces/integration on owned
+
+Only point-to-point neighbour traffic exists; there is no collective in the data path (xGMI is a
+point-to-point fabric, and the halo is O(1-5 MB) per step).  The driver is written against a small "engine"
+interface so the protocol can be exercised on CPU with gloo and a checker engine (tests/test_slab_gloo.py);
+the product engine is HipSlabEngine and has no CPU fallback.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import scene
+from .params import default_params, update_grid
+
+HALO_CELLS = 2
+NO_CUT_LO = -(1 << 29)
+NO_CUT_HI = (1 << 29)
+
+
+def cell_of(x, origin_x, cell_x, real=np.float32):
+    """Unwrapped grid cell-x of positions x, evaluated as the device does (true division in SReal)."""
+    x = np.asarray(x, dtype=real)
+    return np.floor((x - real(origin_x)) / real(cell_x)).astype(np.int64)
+
+
+def plane_cuts(nx_per_rank, world, h, origin_x, real=np.float32):
+    """Cut cells for a lattice that is `world` blocks of nx_per_rank planes long: the cut between rank r-1 and r
+    is the cell containing the mid-point between lattice planes r*nx-1 and r*nx.  Returns world+1 cell indices,
+    open at both ends."""
+    d = float(real(h)) - 0.005
+    cuts = [NO_CUT_LO]
+    for r in range(1, world):
+        xm = (r * nx_per_rank + 0.5) * d
+        cuts.append(int(cell_of([xm], origin_x, h, real)[0]) + 1)
+    cuts.append(NO_CUT_HI)
+    return cuts
+
+
+class HipSlabEngine:
+    """Product engine: particles live in an nrs_ctx on this rank's GPU; buffers are torch CUDA tensors."""
+
+    def __init__(self, params, capacity, msg_capacity, cell_lo, cell_hi, device_index, halo=HALO_CELLS):
+        import torch
+
+        from . import capi
+
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.msg_capacity = int(msg_capacity)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.solver = capi.Solver(params, capacity, solver=capi.SESPH, device=device_index, stream=stream)
+        self.cell_lo, self.cell_hi, self.halo = cell_lo, cell_hi, halo
+        self.msg_bytes = self.solver.message_bytes(self.msg_capacity)
+        self._configured = False
+
+    def make_buffer(self):
+        return self.torch.zeros(self.msg_bytes, dtype=self.torch.uint8, device=self.device)
+
+    def load(self, pos, vel, bi, vbi):
+        self.solver.set_particles(pos, vel)
+        self.solver.set_boundaries(bi, vbi, update_grid=False)
+        self.solver.slab_configure(self.cell_lo, self.cell_hi, self.halo)
+        self._configured = True
+
+    def pack(self, send_left, send_right):
+        return self.solver.slab_pack(None if send_left is None else send_left.data_ptr(),
+                                     None if send_right is None else send_right.data_ptr(), self.msg_capacity)
+
+    def unpack(self, recv_left, recv_right):
+        self.solver.slab_unpack(None if recv_left is None else recv_left.data_ptr(),
+                                None if recv_right is None else recv_right.data_ptr(), self.msg_capacity)
+
+    def step(self, k=1):
+        self.solver.step(k)
+
+    def synchronize(self):
+        self.solver.synchronize()
+
+    @property
+    def n_owned(self):
+        return self.solver.n_owned
+
+    @property
+    def n_local(self):
+        return self.solver.n
+
+    def owned_state(self):
+        """(pos, vel) of the owned particles; valid right after pack()/unpack()."""
+        pos, vel = self.solver.download()
+        k = self.n_owned
+        return pos[:k], vel[:k]
+
+
+class SlabDriver:
+    """Neighbour exchange + step loop for one rank."""
+
+    def __init__(self, engine, rank, world, group=None, stage_through_host=False):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.stage = stage_through_host  # gloo cannot move device tensors: bounce through host copies
+        mk = engine.make_buffer
+        self.send_l = mk() if self.left is not None else None
+        self.recv_l = mk() if self.left is not None else None
+        self.send_r = mk() if self.right is not None else None
+        self.recv_r = mk() if self.right is not None else None
+        self.last_counts = None
+
+    def exchange(self):
+        dist, eng = self.dist, self.engine
+        self.last_counts = eng.pack(self.send_l, self.send_r)
+        ops, host = [], {}
+        def wire(t):
+            if not self.stage or t is None:
+                return t
+            h = t.cpu()
+            host[id(t)] = h
+            return h
+        sl, sr = wire(self.send_l), wire(self.send_r)
+        rl = self.recv_l if not self.stage else (None if self.recv_l is None else self.torch.empty_like(self.recv_l, device="cpu"))
+        rr = self.recv_r if not self.stage else (None if self.recv_r is None else self.torch.empty_like(self.recv_r, device="cpu"))
+        if self.left is not None:
+            ops.append(dist.P2POp(dist.isend, sl, self.left, self.group))
+            ops.append(dist.P2POp(dist.irecv, rl, self.left, self.group))
+        if self.right is not None:
+            ops.append(dist.P2POp(dist.isend, sr, self.right, self.group))
+            ops.append(dist.P2POp(dist.irecv, rr, self.right, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.stage:
+            if rl is not None:
+                self.recv_l.copy_(rl)
+            if rr is not None:
+                self.recv_r.copy_(rr)
+        eng.unpack(self.recv_l, self.recv_r)
+
+    def step(self, k=1):
+        for _ in range(k):
+            self.exchange()
+            self.engine.step(1)
+
+    def finish(self):
+        """Drop halo copies and hand over leavers one last time so that owned_state() is the true partition."""
+        self.exchange()
+
+
+def rank_scene(lattice_per_rank, rank, world, params, real=np.float32, spacing=0.02):
+    """This rank's share of the weak-scaling dam-break: the fluid block is `world` times longer in x; every rank
+    builds only the lattice planes and tank-boundary lattice columns near its slab.  Returns
+    (params_with_global_grid, cuts, pos, vel, bi, vbi, global_counts)."""
+    nx, ny, nz = lattice_per_rank
+    h = float(params["interactionRadius"][0])
+    gnx = nx * world
+    tx, ty, tz = scene.tank_extent(gnx, ny, nz, h, spacing, real)
+    p = params.copy()
+    update_grid(p, (0.0, 0.0, 0.0), (real(tx * spacing), real(ty * spacing), real(tz * spacing)))
+    ox = float(p["worldOrigin"][0][0])
+    cuts = plane_cuts(nx, world, h, ox, real)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    # fluid: my planes +-2, filtered by owning cell
+    plo, phi = max(0, rank * nx - 2), min(gnx, (rank + 1) * nx + 2)
+    pos = scene.fluid_block(gnx, ny, nz, h, real=real, x_range=(plo, phi))
+    cx = cell_of(pos[:, 0], ox, h, real)
+    pos = pos[(cx >= lo) & (cx < hi)]
+    vel = np.zeros_like(pos)
+    # boundary: lattice columns whose cell is within 3 cells of my slab (+3 lattice steps so the Akinci sums of the
+    # kept points are complete)
+    d = float(real(h)) - 0.005
+    x_lo = 0.0 if rank == 0 else (plo + 1) * d - 4 * h
+    x_hi = tx * spacing if rank == world - 1 else (phi) * d + 4 * h
+    i_lo, i_hi = max(0, int(np.floor(x_lo / spacing)) - 3), min(tx, int(np.ceil(x_hi / spacing)) + 3)
+    lat = scene.boundary_box(tx, ty, tz, spacing, i_range=(i_lo, i_hi))
+    vb = scene.akinci_volumes(lat, h, float(params["kpoly"][0]), spacing)
+    keep = (lat[:, 0] >= i_lo + (0 if i_lo == 0 else 3)) & (lat[:, 0] <= i_hi - (0 if i_hi == tx else 3))
+    lat, vb = lat[keep], vb[keep]
+    bi = np.empty((lat.shape[0], 4), dtype=real)
+    bi[:, :3] = (lat.astype(np.float64) * spacing).astype(real)
+    bi[:, 3] = 1.0
+    return p, cuts, pos, vel, bi, vb.astype(real), dict(particles=gnx * ny * nz, tank=(tx, ty, tz))
+
+
+def bench_main(args, lattice, rank, world, local_rank):
+    """bench.py body for WORLD_SIZE > 1 (launched by torchrun, one rank per GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    from . import capi
+    from .params import default_params
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    params = default_params(0)
+    t_gen = time.perf_counter()
+    p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
+    t_gen = time.perf_counter() - t_gen
+    nx, ny, nz = lattice
+    h = float(p["interactionRadius"][0])
+    d = float(np.float32(h)) - 0.005
+    halo_est = int(HALO_CELLS * ny * nz * (h / d) * 1.0)
+    msg_cap = int(1.6 * halo_est) + 8192
+    cap = int(len(pos) * 1.15) + 4 * msg_cap
+    eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank)
+    eng.load(pos, vel, bi, vbi)
+    drv = SlabDriver(eng, rank, world)
+    n_global = info["particles"]
+
+    eng.solver.set_profiling(True)
+    drv.step(args.warmup)
+    eng.synchronize()
+    warm = eng.solver.stage_ms()
+    dominant = max(warm, key=lambda k: warm[k][0]) if warm else "forces"
+    dom_id = {v: k for k, v in capi.STAGE_NAMES.items()}[dominant]
+    eng.solver.set_profiling([dom_id])
+
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dom_ms, dom_launches = 0.0, 0
+    for _ in range(args.steps):
+        drv.exchange()
+        eng.step(1)
+        ms, cnt = eng.solver.stage_ms().get(dominant, (0.0, 0))
+        dom_ms += ms
+        dom_launches += cnt
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    drv.finish()
+    owned = torch.tensor([eng.n_owned], dtype=torch.int64, device="cuda")
+    dist.all_reduce(owned, op=dist.ReduceOp.SUM)
+    finite = np.isfinite(eng.owned_state()[0]).all()
+    ok = torch.tensor([1 if finite else 0], dtype=torch.int64, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(owned.item()) != n_global or int(ok.item()) != 1:
+        raise SystemExit("slab run lost particles or went non-finite: %d of %d" % (int(owned.item()), n_global))
+
+    from bench import HBM_PEAK_GBS, STAGE_BYTES_F32, sesph_bytes_per_particle_step
+
+    num_cells = int(p["numCells"][0])
+    value = n_global * args.steps / dt
+    bpp, passes = sesph_bytes_per_particle_step(num_cells)
+    n_local = eng.n_local
+    dom_bytes = STAGE_BYTES_F32.get(dominant, 0) * n_local
+    dom_avg_ms = dom_ms / max(1, dom_launches)
+    achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
+    out = {
+        "metric": "particle-steps/sec, SESPH dam-break",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "SESPH dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
+                        "x-slabs with a %d-cell halo exchanged per step by RCCL send/recv"
+                        % (nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,),
+            "particles": n_global,
+            "num_cells": num_cells,
+            "steps_per_s": args.steps / dt,
+            "parallelism": "slab x%d" % world,
+            "message_bytes_per_direction": eng.msg_bytes,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_avg_ms": dom_avg_ms,
+            "kernel_launches": dom_launches, "algorithmic_bytes_per_launch": dom_bytes, "rank": 0,
+            "whole_step": {"bytes_per_particle_step": bpp, "radix_passes": passes,
+                           "achieved_per_gpu": bpp * value / world / 1e9, "frac_per_gpu": bpp * value / world / 1e9 / HBM_PEAK_GBS},
+        },
+        "scene_build_s": t_gen,
+    }
+    dist.destroy_process_group()
+    return out
