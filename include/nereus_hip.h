@@ -4,13 +4,9 @@
  *
  * This is the boundary a host program binds (C, C++, ctypes, cgo, JNI ...): plain pointers and sizes,
  * no C++ or torch types.  It REPLACES the reference's CUDA launcher layer, the `extern "C"` block of
- * sph/sph.cuh:19-230 (defined in sph/sph_cuda.cu).  Two flavours are exported:
- *
- *   1. the context API below (nrs_*): device-resident particle state, one call per update();
- *      this is what nereus_amd/host/ (our Nereus::SPH / Nereus::IISPH) and bench.py use;
- *   2. the reference's own entry-point names with their sph.cuh signatures (see the second half of
- *      this header), thin shims over the same kernels, so the reference's unmodified sph.cpp /
- *      iisph.cpp can link against libnereus_hip.so for A/B runs.
+ * sph/sph.cuh:19-230 (defined in sph/sph_cuda.cu), with a context API (nrs_*): device-resident particle
+ * state, one call per update().  It is what nereus_amd/host/ (our Nereus::SPH / Nereus::IISPH) and bench.py
+ * use; INTEGRATION.md maps every reference entry point to its replacement.
  *
  * Conventions: every nrs_* call returns 0 on success, a negative NRS_E_* code otherwise, and
  * nrs_last_error() gives the message (no exceptions cross the ABI).  The caller owns host buffers,

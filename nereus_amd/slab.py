@@ -278,7 +278,7 @@ def bench_main(args, lattice, rank, world, local_rank):
         "config": {
             "workload": "SESPH dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
                         "x-slabs with a %d-cell halo exchanged per step by RCCL send/recv"
-                        % (nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,),
+                        % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,)),
             "particles": n_global,
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
