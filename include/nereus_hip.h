@@ -67,6 +67,8 @@ enum {
     NRS_FLAG_REFERENCE_ORDER = 1u << 0, /* gather kernels walk the 27 cells and sum in exactly the reference's
                                            order (one thread per slot, per-cell partial sums): slower, used for
                                            bit-level comparison with the oracle */
+    NRS_FLAG_NO_FUSION = 1u << 2,       /* keep forces, integrate and hash as three launches (default: a full step
+                                           on the production kernels fuses them into the force kernel) */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };

@@ -108,6 +108,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf posA, posB, velA, velB, presA, presB, dens, forces;
     DevBuf hashA, hashB, indexA, indexB, inv, sortTmp;
     uint32_t *hashCur = nullptr, *indexCur = nullptr; // sorted keys/values after the sort stage
+    bool hashReady = false;                           // the fused force kernel already wrote the next step's keys/values
+    uint32_t *hashNext = nullptr, *indexNext = nullptr;
     DevBuf cellStart, cellEnd, bCellStart, bCellEnd;
     uint32_t cellsAllocated = 0;
     // boundaries
@@ -123,6 +125,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     uint64_t nOwned = 0;
     uint32_t ghostCount = 0;
     bool cellsClean = false; // cellStart is all-EMPTY
+    bool fusedThisStep = false;
     // profiling
     struct Ev { int stage; hipEvent_t a, b; };
     std::vector<Ev> evPool;
@@ -175,7 +178,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         cfg = c;
         cap = c.capacity;
-        if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "capacity must be in 1..2^30-1");
+        if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "capacity must be in 1..2^27-1");
         std::memcpy(&P, params, sizeof(P));
         const size_t v = sizeof(T4) * cap, s = sizeof(R) * cap, u = 4 * cap;
         NRSCHK(posA.alloc(v)); NRSCHK(posB.alloc(v)); NRSCHK(velA.alloc(v)); NRSCHK(velB.alloc(v));
@@ -211,6 +214,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         Params<R> q;
         std::memcpy(&q, params, sizeof(q));
         const bool regrid = q.numCells != P.numCells;
+        if (std::memcmp(&P, &q, sizeof(P)) != 0) hashReady = false; // grid/origin may have changed: re-hash
         P = q;
         if (regrid) {
             NRSCHK(alloc_cells());
@@ -238,11 +242,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         }
         if (first + count > n) n = first + count;
         midStep = false;
+        hashReady = false;
         return NRS_OK;
     }
     int set_n(uint64_t nn) override
     {
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
+        if (nn != n) hashReady = false;
         n = nn;
         return NRS_OK;
     }
@@ -293,7 +299,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int set_boundaries(const void *bi4, const void *vbi, uint64_t nbNew, int update_grid) override
     {
-        if (nbNew > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "too many boundary particles (max 2^30-1)");
+        if (nbNew > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "too many boundary particles (max 2^27-1)");
         if (nbNew && (!bi4 || !vbi)) return fail(NRS_E_INVALID, "bi4/vbi is NULL");
         nb = nbNew;
         hostBi.assign((const T4 *)bi4, (const T4 *)bi4 + nb);
@@ -393,15 +399,24 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         const uint32_t N = (uint32_t)n;
         const dim3 g(nblocks(N)), b(BLOCK);
-        NRSCHK(ev_begin(NRS_STAGE_HASH));
-        hipLaunchKernelGGL((k_hash<R>), g, b, 0, stream, P, posA.as<T4>(), hashA.as<uint32_t>(), indexA.as<uint32_t>(), N);
-        NRSCHK(ev_end());
-        hashCur = hashA.as<uint32_t>(); indexCur = indexA.as<uint32_t>();
+        uint32_t *kIn = hashA.as<uint32_t>(), *kAlt = hashB.as<uint32_t>();
+        uint32_t *vIn = indexA.as<uint32_t>(), *vAlt = indexB.as<uint32_t>();
+        if (hashReady) { // keys/values of this step were produced by the previous step's fused force kernel
+            kIn = hashNext; vIn = indexNext;
+            kAlt = (kIn == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+            vAlt = (vIn == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+        } else {
+            NRSCHK(ev_begin(NRS_STAGE_HASH));
+            hipLaunchKernelGGL((k_hash<R>), g, b, 0, stream, P, posA.as<T4>(), kIn, vIn, N);
+            NRSCHK(ev_end());
+        }
+        hashReady = false;
+        hashCur = kIn; indexCur = vIn;
         if (stop == NRS_STAGE_HASH) return NRS_OK;
 
         NRSCHK(ev_begin(NRS_STAGE_SORT));
-        rocprim::double_buffer<uint32_t> k(hashA.as<uint32_t>(), hashB.as<uint32_t>());
-        rocprim::double_buffer<uint32_t> v(indexA.as<uint32_t>(), indexB.as<uint32_t>());
+        rocprim::double_buffer<uint32_t> k(kIn, kAlt);
+        rocprim::double_buffer<uint32_t> v(vIn, vAlt);
         size_t tmp = sortTmp.bytes;
         HIPCHK(rocprim::radix_sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, 0u, sort_end_bit(), stream));
         hashCur = k.current(); indexCur = v.current();
@@ -432,15 +447,29 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slabOn) { G.actLo = slab.lo; G.actHi = slab.hi; }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_DENSITY) return NRS_OK;
+        // A full step on the production kernels fuses forces + integrate + next-step hash into one launch that
+        // writes the new state straight into the A ("current") arrays, which reorder has finished reading.
+        const bool fuse = !refOrder() && stop == 0 && !(cfg.flags & NRS_FLAG_NO_FUSION);
         NRSCHK(ev_begin(NRS_STAGE_FORCES));
-        if (refOrder())
+        if (refOrder()) {
             hipLaunchKernelGGL((k_forces_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), velB.as<T4>(),
                                dens.as<R>(), presB.as<R>(), forces.as<T4>(), N);
-        else
+        } else if (fuse) {
+            FusedOut<R> fo;
+            fo.newPos = posA.as<T4>(); fo.newVel = velA.as<T4>();
+            fo.hash = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+            fo.index = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), velB.as<T4>(), dens.as<R>(),
-                                                      presB.as<R>(), forces.as<T4>(), N);
+                                                      presB.as<R>(), (T4 *)nullptr, &fo, N);
+            hashNext = fo.hash; indexNext = fo.index;
+            hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
+            fusedThisStep = true;
+        } else {
+            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), velB.as<T4>(), dens.as<R>(),
+                                                      presB.as<R>(), forces.as<T4>(), (const FusedOut<R> *)nullptr, N);
+        }
         NRSCHK(ev_end());
-        if (stop == NRS_STAGE_FORCES) return NRS_OK;
+        if (stop == NRS_STAGE_FORCES || fuse) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_INTEGRATE));
         hipLaunchKernelGGL((k_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), forces.as<T4>(), N);
         NRSCHK(ev_end());
@@ -578,6 +607,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if ((uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > cap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > cap || tot[ST_GHOST] > cap)
             return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
         if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
+        hashReady = false;
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];
@@ -623,6 +653,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (n == 0) return NRS_OK;
         if (profMask) { std::memset(stageMs, 0, sizeof(stageMs)); std::memset(stageLaunches, 0, sizeof(stageLaunches)); }
         for (int s = 0; s < nsteps; ++s) {
+            fusedThisStep = false;
             NRSCHK(stage_prefix(stop));
             if (stop && stop <= NRS_STAGE_REORDER) { midStep = true; break; }
             if (iisph()) { if (nb) NRSCHK(iisph_tail<true>(stop)); else NRSCHK(iisph_tail<false>(stop)); }
@@ -634,8 +665,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 cellsClean = true;
             }
             // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
-            std::swap(posA.p, posB.p);
-            std::swap(velA.p, velB.p);
+            if (!fusedThisStep) { // the fused kernel already wrote the new state into A
+                std::swap(posA.p, posB.p);
+                std::swap(velA.p, velB.p);
+            }
             if (iisph()) std::swap(presA.p, presB.p);
         }
         HIPCHK(hipGetLastError());

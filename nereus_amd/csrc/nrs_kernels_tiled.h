@@ -7,13 +7,17 @@
 //
 //   scan    walk the 9 (dz,dy) rows; the three x-cells of a row are ONE contiguous run of the sorted array
 //           (hash = (z*gy+y)*gx+x), so a row is a single [lo,hi) sweep of float4 positions with a
-//           squared-distance compare against a precomputed threshold (no sqrt, no divide).  Hits are
-//           appended to a per-thread list kept in LDS (lst[k][tid], k-major: conflict-free).
+//           squared-distance compare against a precomputed threshold (no sqrt, no divide).  The loop is
+//           organised for memory-level parallelism (measured: the plain cell walk is latency-bound with one
+//           dependent load in flight per thread): 27 table entries per z-plane requested at once, candidate
+//           positions fetched 8 at a time.  Hits are appended to a per-thread list kept in LDS
+//           (lst[k][tid], k-major: conflict-free).
 //   process the compacted hits (nearly equal counts across lanes → dense wavefronts) get the expensive
 //           kernel evaluation, in the same order the reference visits them.
 //
 // Every floating-point sum is formed in the reference's order (per-cell partial sums for the density,
-// running sums for the forces; flags in the hit list mark partial-sum boundaries), so the results are
+// running sums for the forces; every hit carries its cell number, fluid and boundary hits are merged back
+// into the reference's cell-by-cell order), so the results are
 // bit-identical to the reference-order kernels in nrs_kernels_ref.h — which are also the overflow path
 // for a thread whose hit list would exceed HIT_CAP (correct for any neighbour count).
 //
@@ -23,10 +27,11 @@
 
 namespace nrs {
 
-constexpr int HIT_CAP = 32;                 // hits kept per thread (LDS: HIT_CAP*BLOCK*4 B = 32 KiB per workgroup)
-constexpr uint32_t HIT_BOUNDARY = 1u << 31; // entry refers to a boundary particle
-constexpr uint32_t HIT_NEWPART = 1u << 30;  // a partial-sum boundary was crossed since the previous hit
-constexpr uint32_t HIT_INDEX = (1u << 30) - 1;
+constexpr int HIT_CAP = 32; // hits kept per thread (LDS: HIT_CAP*BLOCK*4 B = 32 KiB per workgroup)
+// A hit is one u32: bits 31..27 = neighbour-cell number 0..26 in the reference's z,y,x visiting order,
+// bits 26..0 = index into the sorted fluid array (or the sorted boundary array).
+constexpr uint32_t HIT_INDEX = (1u << 27) - 1;
+constexpr int HIT_TAG_SHIFT = 27;
 
 // Thresholds that turn the reference's two cut-off predicates into one float compare on the float dot
 // product d2 = dot(r,r)  (exact: sqrtf and the products are monotone, correctly rounded):
@@ -34,96 +39,261 @@ constexpr uint32_t HIT_INDEX = (1u << 30) - 1;
 //   r2LeH2  : smallest float T with  fl(sqrtf(T)^2) > h*h    ⇒  !(length(r)^2 > h^2)     ⇔ d2 < T
 struct CutThresholds { float lenLtIr, r2LeH2; };
 
+constexpr int SCAN_BATCH = 8; // candidate positions fetched per thread per memory round trip
+
+// Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
+// lst[HIT_CAP-1 .. HIT_CAP-nb] (descending slots, ascending visiting order); both lists are ordered by cell
+// number, so the process phase restores the reference's order (cell by cell: fluid, then boundary) by merging.
+struct HitCounts { int nf, nb; bool over; };
+
 template <typename R> struct Sweep {
     typedef typename Vec4T<R>::type T4;
 
-    // Scan the neighbourhood of `self`; returns the hit count, or -1 when the list overflowed.
     // BFILT: cut-off used for boundary candidates: 0 = lenLtIr (explicit test of the density loop); 1 = r2LeH2
     // (the force loop has no explicit test, but every Muller kernel it evaluates returns 0 beyond h);
     // 2 = none (Monaghan kernels reach 2h, so every boundary particle of the 27 cells contributes).
-    template <bool HAS_B, int BFILT>
-    static NRS_DEV int scan(const Params<R> &P, const GridView<R> &G, const CutThresholds thr,
-                            const T4 *__restrict__ sPos, uint32_t self, V3<R> p, uint32_t (*lst)[BLOCK])
+    //
+    // The loop is built for memory-level parallelism and few branches (profiled: the plain cell walk keeps one
+    // dependent load in flight per thread, and a branchy scan spends as many scalar exec-mask instructions as
+    // vector ones): the cell-table entries of a whole z-plane (3 rows x 3 cells, start and end) are requested
+    // together; the three x-cells of a row are ONE run [lo,hi) of the sorted array; candidate positions are
+    // fetched SCAN_BATCH at a time and tested branch-free; only the (rare) hit takes a branch.  Boundary cells
+    // are swept afterwards, only by the lanes that have any, so the fluid sweep stays uniform across the wave.
+    template <bool HAS_B, int BFILT, int W>
+    static NRS_DEV HitCounts scan(const Params<R> &P, const GridView<R> &G, const CutThresholds thr,
+                                  const T4 *__restrict__ sPos, uint32_t self, V3<R> p, uint32_t (*lst)[W])
     {
         const I3 gp = calcGridPos<R>(P, p);
         const uint32_t mx = P.gridSize[0] - 1, my = P.gridSize[1] - 1, mz = P.gridSize[2] - 1;
         const uint32_t cx = (uint32_t)gp.x & mx;
+        const uint32_t x0 = (cx - 1u) & mx, x2 = (cx + 1u) & mx;
         const bool contiguous = (cx >= 1u) && (cx + 1u <= mx);
         const float tF = thr.lenLtIr;
         const float tB = BFILT == 2 ? INFINITY : (BFILT == 1 ? thr.r2LeH2 : thr.lenLtIr);
         const uint32_t tid = threadIdx.x;
-        int cnt = 0;
-        uint32_t pend = HIT_NEWPART;
+        int nf = 0, nb = 0;
         bool over = false;
 
-        auto testFluid = [&](uint32_t j) {
-            if (j != self) {
-                const V3<R> d = p - xyz<R>(sPos[j]);
-                if (dot(d, d) < tF) {
-                    if (cnt < HIT_CAP) lst[cnt][tid] = j | pend; else over = true;
-                    ++cnt;
-                    pend = 0;
+        // fluid candidates j in [a, b); the cell number advances at j == m1 and j == m2 (starts of the 2nd / 3rd
+        // cell of a merged run; CELL_EMPTY when that cell is empty)
+        auto sweepFluid = [&](uint32_t a, uint32_t b, uint32_t m1, uint32_t m2, uint32_t tag0) {
+            const uint32_t nT = b - a;
+            for (uint32_t base = 0; base < nT; base += SCAN_BATCH) {
+                T4 c[SCAN_BATCH];
+#pragma unroll
+                for (int u = 0; u < SCAN_BATCH; ++u) c[u] = sPos[a + min(base + (uint32_t)u, nT - 1u)];
+#pragma unroll
+                for (int u = 0; u < SCAN_BATCH; ++u) {
+                    const uint32_t q = base + (uint32_t)u;
+                    const uint32_t j = a + q;
+                    const V3<R> d = p - xyz<R>(c[u]);
+                    const bool hit = (q < nT) & (j != self) & (dot(d, d) < tF);
+                    if (hit) {
+                        uint32_t tag = tag0 + ((m1 != CELL_EMPTY) & (j >= m1) ? 1u : 0u);
+                        if ((m2 != CELL_EMPTY) & (j >= m2)) tag = tag0 + 2u;
+                        if (nf + nb < HIT_CAP) lst[nf][tid] = j | (tag << HIT_TAG_SHIFT); else over = true;
+                        ++nf;
+                    }
                 }
-            }
-        };
-        auto testBoundary = [&](uint32_t j) {
-            const V3<R> d = p - xyz<R>(G.sB[j]);
-            if (dot(d, d) < tB) {
-                if (cnt < HIT_CAP) lst[cnt][tid] = j | pend | HIT_BOUNDARY; else over = true;
-                ++cnt;
-                pend = 0;
             }
         };
 
         for (int z = -1; z <= 1; z++) {
             const uint32_t cz = (uint32_t)(gp.z + z) & mz;
-            for (int y = -1; y <= 1; y++) {
-                const uint32_t cy = (uint32_t)(gp.y + y) & my;
-                const uint32_t row = umul24(umul24(cz, P.gridSize[1]), P.gridSize[0]) + umul24(cy, P.gridSize[0]);
-                const uint32_t h0 = row + ((cx - 1u) & mx), h1 = row + cx, h2 = row + ((cx + 1u) & mx);
-                const uint32_t s0 = G.cellStart[h0], s1 = G.cellStart[h1], s2 = G.cellStart[h2];
-                bool anyB = false;
-                uint32_t b0 = CELL_EMPTY, b1 = CELL_EMPTY, b2 = CELL_EMPTY;
-                if (HAS_B) {
-                    b0 = G.bCellStart[h0]; b1 = G.bCellStart[h1]; b2 = G.bCellStart[h2];
-                    anyB = (b0 & b1 & b2) != CELL_EMPTY;
+            const uint32_t plane = umul24(umul24(cz, P.gridSize[1]), P.gridSize[0]);
+            // all table entries of this z-plane in one go: 3 rows x {start,end} x 3 cells (+ boundary starts)
+            uint32_t st[3][3], en[3][3], hrow[3];
+            uint32_t bmask = 0; // bit (y*3+c): boundary particles in that cell
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const uint32_t cy = (uint32_t)(gp.y + y - 1) & my;
+                hrow[y] = plane + umul24(cy, P.gridSize[0]);
+                const uint32_t h[3] = {hrow[y] + x0, hrow[y] + cx, hrow[y] + x2};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    st[y][c] = G.cellStart[h[c]];
+                    en[y][c] = G.cellEnd[h[c]];
+                    if (HAS_B) bmask |= (G.bCellStart[h[c]] != CELL_EMPTY) ? (1u << (y * 3 + c)) : 0u;
                 }
-                if (contiguous && !anyB) {
+            }
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const uint32_t tag0 = (uint32_t)((z + 1) * 9 + y * 3);
+                const uint32_t s0 = st[y][0], s1 = st[y][1], s2 = st[y][2];
+                if (contiguous) {
                     // one contiguous run of the sorted array: [first non-empty start, last non-empty end)
-                    uint32_t lo, hi;
-                    if (s2 != CELL_EMPTY) hi = G.cellEnd[h2];
-                    else if (s1 != CELL_EMPTY) hi = G.cellEnd[h1];
-                    else if (s0 != CELL_EMPTY) hi = G.cellEnd[h0];
-                    else hi = 0;
-                    lo = (s0 != CELL_EMPTY) ? s0 : ((s1 != CELL_EMPTY) ? s1 : s2);
-                    if (lo == CELL_EMPTY) hi = 0;
-                    pend = HIT_NEWPART;
-                    for (uint32_t j = lo; j < hi; ++j) {
-                        if (j == s1 || j == s2) pend = HIT_NEWPART;
-                        testFluid(j);
-                    }
-                } else {
-                    const uint32_t hs[3] = {h0, h1, h2}, ss[3] = {s0, s1, s2}, bs[3] = {b0, b1, b2};
-                    for (int c = 0; c < 3; ++c) {
-                        pend = HIT_NEWPART;
-                        if (ss[c] != CELL_EMPTY) {
-                            const uint32_t e = G.cellEnd[hs[c]];
-                            for (uint32_t j = ss[c]; j < e; ++j) testFluid(j);
-                        }
-                        if (HAS_B) {
-                            pend = HIT_NEWPART;
-                            if (bs[c] != CELL_EMPTY) {
-                                const uint32_t e = G.bCellEnd[hs[c]];
-                                for (uint32_t j = bs[c]; j < e; ++j) testBoundary(j);
+                    uint32_t lo = (s0 != CELL_EMPTY) ? s0 : ((s1 != CELL_EMPTY) ? s1 : s2);
+                    uint32_t hi = (s2 != CELL_EMPTY) ? en[y][2] : ((s1 != CELL_EMPTY) ? en[y][1] : en[y][0]);
+                    if (lo == CELL_EMPTY) lo = hi = 0;
+                    sweepFluid(lo, hi, s1, s2, tag0);
+                } else { // the 3-cell window wraps around the grid edge: cell by cell
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (st[y][c] != CELL_EMPTY) sweepFluid(st[y][c], en[y][c], CELL_EMPTY, CELL_EMPTY, tag0 + (uint32_t)c);
+                }
+            }
+            if (HAS_B) {
+                // boundary cells of this plane, visited in ascending cell number by the lanes that have any
+                while (bmask) {
+                    const int bit = __builtin_ctz(bmask);
+                    bmask &= bmask - 1u;
+                    const int y = bit / 3, c = bit - y * 3;
+                    const uint32_t cy = (uint32_t)(gp.y + y - 1) & my;
+                    const uint32_t hc = plane + umul24(cy, P.gridSize[0]) + (c == 0 ? x0 : (c == 1 ? cx : x2));
+                    const uint32_t a = G.bCellStart[hc], nT = G.bCellEnd[hc] - a;
+                    const uint32_t tag = (uint32_t)((z + 1) * 9 + bit);
+                    for (uint32_t base = 0; base < nT; base += 4) {
+                        T4 cb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cb[u] = G.sB[a + min(base + (uint32_t)u, nT - 1u)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t q = base + (uint32_t)u;
+                            const V3<R> d = p - xyz<R>(cb[u]);
+                            if ((q < nT) & (dot(d, d) < tB)) {
+                                if (nf + nb < HIT_CAP) lst[HIT_CAP - 1 - nb][tid] = (a + q) | (tag << HIT_TAG_SHIFT); else over = true;
+                                ++nb;
                             }
                         }
                     }
                 }
             }
         }
-        return over ? -1 : cnt;
+        HitCounts hc;
+        hc.nf = nf; hc.nb = nb; hc.over = over;
+        return hc;
     }
 };
+
+// Merge cursor over the two hit lists: yields hits in the reference's order (cell 0 fluid, cell 0 boundary,
+// cell 1 fluid, ...).  key = 2*cell + kind identifies the partial sum a hit belongs to.
+template <int W> struct HitMerge {
+    uint32_t (*lst)[W];
+    uint32_t tid;
+    int nf, nb, kf, kb;
+    NRS_DEV HitMerge(uint32_t (*l)[W], uint32_t t, HitCounts hc) : lst(l), tid(t), nf(hc.nf), nb(hc.nb), kf(0), kb(0) {}
+    NRS_DEV bool next(uint32_t &index, bool &boundary, uint32_t &key)
+    {
+        if (kf >= nf && kb >= nb) return false;
+        const uint32_t ef = kf < nf ? lst[kf][tid] : 0xffffffffu;
+        const uint32_t eb = kb < nb ? lst[HIT_CAP - 1 - kb][tid] : 0xffffffffu;
+        const uint32_t tf = ef >> HIT_TAG_SHIFT, tb = eb >> HIT_TAG_SHIFT;
+        boundary = tb < tf; // fluid first inside a cell; the 0xffffffff sentinel has tag 31 > 26
+        const uint32_t e = boundary ? eb : ef;
+        if (boundary) ++kb; else ++kf;
+        index = e & HIT_INDEX;
+        key = (e >> HIT_TAG_SHIFT) * 2u + (boundary ? 1u : 0u);
+        return true;
+    }
+};
+
+// ---- phase 2 of the density (computeDensityPressure, sph_kernel_impl.cuh:365-433): hits → rho -----------
+template <typename R, int KSET, bool HAS_B, int W>
+NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const typename Vec4T<R>::type *__restrict__ sPos,
+                            V3<R> p, uint32_t (*lst)[W], uint32_t tid, HitCounts hc)
+{
+    const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
+    R d = (R)0.0;
+    d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
+    R part = (R)0.0; // the reference adds one partial sum per (cell, fluid|boundary)
+    uint32_t prevKey = 0xffffffffu;
+    HitMerge<W> it(lst, tid, hc);
+    uint32_t j, key;
+    bool isB;
+    while (it.next(j, isB, key)) {
+        if (key != prevKey) { d += part; part = (R)0.0; prevKey = key; }
+        if (HAS_B && isB) {
+            const typename Vec4T<R>::type b = G.sB[j];
+            const V3<R> r = p - xyz<R>(b);
+            const R psi = rd * b.w;
+            part += (psi * W_dens<R, KSET>(r, ir, kp));
+        } else {
+            const V3<R> r = p - xyz<R>(sPos[j]);
+            part += (pm * W_dens<R, KSET>(r, ir, kp));
+        }
+    }
+    d += part;
+    return d;
+}
+
+// ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
+template <typename R, int KSET, bool SURF, bool HAS_B, int W>
+NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
+                                     const typename Vec4T<R>::type *__restrict__ sPos,
+                                     const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
+                                     const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
+                                     uint32_t (*lst)[W], uint32_t tid, HitCounts hc)
+{
+    ForceAcc<R> A;
+    A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
+    const R pm = P.particleMass, m2 = P.particleMass, ir = P.interactionRadius, kp = P.kpoly;
+    const R kappa = P.surfaceTension;
+    const R kprg = P.kpress_grad, kvg = P.kvisc_grad, kvd = P.kvisc_denum;
+    const R diameter = (R)(2.0 * P.particleRadius);
+    const R diameter2 = diameter * diameter;
+    const R d1sq = dens * dens;
+    R kernel_diameter;
+    if (KSET == KS_MONAGHAN) kernel_diameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
+    else kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
+    const R epsilon = (R)0.01;
+    const R beta = P.beta, rd = P.restDensity;
+    HitMerge<W> it(lst, tid, hc);
+    uint32_t j, key;
+    bool isB;
+    while (it.next(j, isB, key)) {
+        if (HAS_B && isB) {
+            const typename Vec4T<R>::type bq = G.sB[j];
+            const R psi = (rd * bq.w);
+            const V3<R> p1p2 = pos1 - xyz<R>(bq);
+            const V3<R> v1v2 = vel1;
+            R kernel;
+            V3<R> grad;
+            if (KSET == KS_MONAGHAN) {
+                kernel = Wmonaghan<R>(p1p2, ir);
+                grad = Wmonaghan_grad<R>(p1p2, ir);
+            } else {
+                kernel = Wdefault<R>(p1p2, ir, P.kpoly);
+                grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+            }
+            A.fbound = A.fbound + (beta * psi * p1p2 * kernel);
+            A.fpres = A.fpres + (-pm * psi * (pres / (dens * dens)) * grad);
+            const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
+            const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
+            const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
+            const R Pij = -nu * (nom / denom);
+            A.fvisc = A.fvisc - (pm * psi * Pij * grad);
+        } else {
+            const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
+            const R dens2 = sDens[j];
+            const R pres2 = sPres[j];
+            const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
+            const R d2sq = dens2 * dens2;
+            V3<R> kpressure_grad, kvisco_grad;
+            R kernel;
+            if (KSET == KS_MONAGHAN) {
+                kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
+                kvisco_grad = kpressure_grad;
+                kernel = Wmonaghan<R>(p1p2, ir);
+            } else {
+                kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
+                kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
+                kernel = Wdefault<R>(p1p2, ir, kp);
+            }
+            A.fpres = A.fpres + (m2 * (pres / d1sq + pres2 / d2sq) * kpressure_grad);
+            const R a = dot(p1p2, kvisco_grad);
+            const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
+            A.fvisc = A.fvisc + (m2 / dens2 * v1v2 * (a / b));
+            if (SURF) {
+                V3<R> ai = mk3<R>(0, 0, 0);
+                const R r2 = dot(p1p2, p1p2);
+                if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
+                else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+                A.fsurf = A.fsurf + ai;
+            }
+        }
+    }
+    return A;
+}
 
 // ---- density + Tait pressure (computeDensityPressure, sph_kernel_impl.cuh:365-433) -----------------------
 template <typename R, int KSET, bool HAS_B>
@@ -137,126 +307,64 @@ __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R
     const uint32_t tid = threadIdx.x;
     const V3<R> p = xyz<R>(sPos[i]);
     if (!slab_active<R>(P, G, p.x)) { dens[i] = (R)0; if (pres) pres[i] = (R)0; return; }
-    const int cnt = Sweep<R>::template scan<HAS_B, 0>(P, G, thr, sPos, i, p, lst);
+    const HitCounts hc = Sweep<R>::template scan<HAS_B, 0, BLOCK>(P, G, thr, sPos, i, p, lst);
     R d;
-    if (cnt < 0) {
-        d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // overflow: reference-order path
-    } else {
-        const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
-        d = (R)0.0;
-        d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
-        R part = (R)0.0;
-        for (int k = 0; k < cnt; ++k) {
-            const uint32_t ent = lst[k][tid];
-            if (ent & HIT_NEWPART) { d += part; part = (R)0.0; }
-            const uint32_t j = ent & HIT_INDEX;
-            if (HAS_B && (ent & HIT_BOUNDARY)) {
-                const typename Vec4T<R>::type b = G.sB[j];
-                const V3<R> r = p - xyz<R>(b);
-                const R psi = rd * b.w;
-                part += (psi * W_dens<R, KSET>(r, ir, kp));
-            } else {
-                const V3<R> r = p - xyz<R>(sPos[j]);
-                part += (pm * W_dens<R, KSET>(r, ir, kp));
-            }
-        }
-        d += part;
-    }
+    if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
+    else d = density_from_hits<R, KSET, HAS_B, BLOCK>(P, G, sPos, p, lst, tid, hc);
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
 }
 
-// ---- forces (computeForces + computeCellForces, sph_kernel_impl.cuh:442-680) -----------------------------
-template <typename R, int KSET, bool SURF, bool HAS_B>
+// ---- forces (computeForces, sph_kernel_impl.cuh:609-680).  FUSE: the same launch also integrates
+//      (integrate_functor :71-100) and hashes the new position (calcHashD :127-145), writing the next step's input
+//      arrays and radix-sort keys directly: saves the force-array round trip and two launches per step ---------
+template <typename R> struct FusedOut {
+    typedef typename Vec4T<R>::type T4;
+    T4 *newPos, *newVel;    // next step's "unsorted" arrays
+    uint32_t *hash, *index; // next step's keys / values
+};
+
+template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
 __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const typename Vec4T<R>::type *__restrict__ sVel,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,
-                                                        typename Vec4T<R>::type *__restrict__ forces, uint32_t n)
+                                                        typename Vec4T<R>::type *__restrict__ forces, FusedOut<R> fo,
+                                                        uint32_t n)
 {
+    typedef typename Vec4T<R>::type T4;
     __shared__ uint32_t lst[HIT_CAP][BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t tid = threadIdx.x;
-    const V3<R> pos1 = xyz<R>(sPos[i]);
-    if (!slab_active<R>(P, G, pos1.x)) { forces[i] = mk4<R>((R)0, (R)0, (R)0, (R)0); return; }
-    const V3<R> vel1 = xyz<R>(sVel[i]);
-    const R dens = sDens[i], pres = sPres[i];
-    const int cnt = Sweep<R>::template scan<HAS_B, (KSET == KS_MULLER ? 1 : 2)>(P, G, thr, sPos, i, pos1, lst);
-    ForceAcc<R> A;
-    if (cnt < 0) {
-        A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-    } else {
-        A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
-        const R pm = P.particleMass, m2 = P.particleMass, ir = P.interactionRadius, kp = P.kpoly;
-        const R kappa = P.surfaceTension;
-        const R kprg = P.kpress_grad, kvg = P.kvisc_grad, kvd = P.kvisc_denum;
-        const R diameter = (R)(2.0 * P.particleRadius);
-        const R diameter2 = diameter * diameter;
-        const R d1sq = dens * dens;
-        R kernel_diameter;
-        if (KSET == KS_MONAGHAN) kernel_diameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
-        else kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
-        const R epsilon = (R)0.01;
-        const R beta = P.beta, rd = P.restDensity;
-        for (int k = 0; k < cnt; ++k) {
-            const uint32_t ent = lst[k][tid];
-            const uint32_t j = ent & HIT_INDEX;
-            if (HAS_B && (ent & HIT_BOUNDARY)) {
-                const typename Vec4T<R>::type bq = G.sB[j];
-                const R psi = (rd * bq.w);
-                const V3<R> p1p2 = pos1 - xyz<R>(bq);
-                const V3<R> v1v2 = vel1;
-                R kernel;
-                V3<R> grad;
-                if (KSET == KS_MONAGHAN) {
-                    kernel = Wmonaghan<R>(p1p2, ir);
-                    grad = Wmonaghan_grad<R>(p1p2, ir);
-                } else {
-                    kernel = Wdefault<R>(p1p2, ir, P.kpoly);
-                    grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
-                }
-                A.fbound = A.fbound + (beta * psi * p1p2 * kernel);
-                A.fpres = A.fpres + (-pm * psi * (pres / (dens * dens)) * grad);
-                const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
-                const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
-                const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
-                const R Pij = -nu * (nom / denom);
-                A.fvisc = A.fvisc - (pm * psi * Pij * grad);
-            } else {
-                const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
-                const R dens2 = sDens[j];
-                const R pres2 = sPres[j];
-                const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
-                const R d2sq = dens2 * dens2;
-                V3<R> kpressure_grad, kvisco_grad;
-                R kernel;
-                if (KSET == KS_MONAGHAN) {
-                    kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
-                    kvisco_grad = kpressure_grad;
-                    kernel = Wmonaghan<R>(p1p2, ir);
-                } else {
-                    kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
-                    kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
-                    kernel = Wdefault<R>(p1p2, ir, kp);
-                }
-                A.fpres = A.fpres + (m2 * (pres / d1sq + pres2 / d2sq) * kpressure_grad);
-                const R a = dot(p1p2, kvisco_grad);
-                const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
-                A.fvisc = A.fvisc + (m2 / dens2 * v1v2 * (a / b));
-                if (SURF) {
-                    V3<R> ai = mk3<R>(0, 0, 0);
-                    const R r2 = dot(p1p2, p1p2);
-                    if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
-                    else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
-                    A.fsurf = A.fsurf + ai;
-                }
-            }
-        }
+    const T4 p4 = sPos[i];
+    const T4 v4 = sVel[i];
+    const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
+    V3<R> f = mk3<R>(0, 0, 0);
+    if (slab_active<R>(P, G, pos1.x)) {
+        const R dens = sDens[i], pres = sPres[i];
+        constexpr int BF = (KSET == KS_MULLER ? 1 : 2);
+        const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK>(P, G, thr, sPos, i, pos1, lst);
+        ForceAcc<R> A;
+        if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B, BLOCK>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, lst, tid, hc);
+        f = sesph_total_force<R>(P, A, dens);
     }
-    const V3<R> f = sesph_total_force<R>(P, A, dens);
-    forces[i] = mk4<R>(f, (R)0);
+    if (forces) forces[i] = mk4<R>(f, (R)0);
+    if (FUSE) {
+        const R dt = P.timestep, m1 = P.particleMass;
+        const V3<R> accel = dt * f / m1;
+        const V3<R> v = vel1 + accel;
+        const V3<R> pn = pos1 + dt * v;
+        fo.newPos[i] = mk4<R>(pn, p4.w);
+        fo.newVel[i] = mk4<R>(v, v4.w);
+        const I3 g = calcGridPos<R>(P, pn);
+        fo.hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
+        fo.index[i] = i;
+    }
 }
+
+static inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 // host-side threshold search (IEEE float arithmetic on the host)
 template <typename R> static inline CutThresholds make_thresholds(const Params<R> &P)
@@ -281,26 +389,30 @@ template <typename R> static inline CutThresholds make_thresholds(const Params<R
     return t;
 }
 
-static inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
-
 template <typename R, int KSET, bool HAS_B>
-static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G,
-                                        const uint32_t * /*hashSorted*/, const typename Vec4T<R>::type *sPos, R *dens,
-                                        R *pres, uint32_t n)
+static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const uint32_t * /*hashSorted*/,
+                                        const typename Vec4T<R>::type *sPos, R *dens, R *pres, uint32_t n)
 {
     const CutThresholds thr = make_thresholds<R>(P);
-    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr,
-                       sPos, dens, pres, n);
+    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr, sPos,
+                       dens, pres, n);
 }
 template <typename R, int KSET, bool SURF, bool HAS_B>
-static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G,
-                                       const uint32_t * /*hashSorted*/, const typename Vec4T<R>::type *sPos,
-                                       const typename Vec4T<R>::type *sVel, const R *dens, const R *pres,
-                                       typename Vec4T<R>::type *forces, uint32_t n)
+static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const uint32_t * /*hashSorted*/,
+                                       const typename Vec4T<R>::type *sPos, const typename Vec4T<R>::type *sVel, const R *dens,
+                                       const R *pres, typename Vec4T<R>::type *forces, const FusedOut<R> *fused, uint32_t n)
 {
     const CutThresholds thr = make_thresholds<R>(P);
-    hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G,
-                       thr, sPos, sVel, dens, pres, forces, n);
+    FusedOut<R> fo;
+    fo.newPos = fo.newVel = nullptr;
+    fo.hash = fo.index = nullptr;
+    const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
+    if (fused) {
+        fo = *fused;
+        hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
+    } else {
+        hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
+    }
 }
 
 } // namespace nrs

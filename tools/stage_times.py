@@ -1,0 +1,20 @@
+"""Print per-stage HIP-event times for a scene (GPU box)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nereus_amd import capi, scene
+from nereus_amd.params import default_params
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+p = default_params(0)
+lat = scene.CONFIGS[cfg] if cfg in scene.CONFIGS else tuple(int(v) for v in cfg.split(","))
+sc = scene.dam_break(lat, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+s = capi.Solver(p, len(sc["pos"]), reference_order=bool(os.environ.get("REF")))
+s.set_particles(sc["pos"], sc["vel"]); s.set_boundaries(sc["bi"], sc["vbi"], True)
+s.step(5); s.set_profiling(True); s.step(steps); s.synchronize()
+t = s.stage_ms()
+print(cfg, "dbg", os.environ.get("NEREUS_DBG_STOP"), {k: round(v[0] / v[1], 4) for k, v in t.items()}, "total/step", round(sum(v[0] for v in t.values()) / steps, 4))
+if not os.environ.get("NEREUS_DBG_STOP"):
+    d = s.get("dens"); print("dens mean", d.mean())
+else:
+    s.set_particles(sc["pos"], sc["vel"]); s.step_partial(capi.STAGE_DENSITY); d = s.get("dens"); print("dbg dens mean", d.mean(), "min", d.min(), "max", d.max())
