@@ -32,6 +32,23 @@ HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 meas
 # algorithmic bytes per particle per launch of each stage (V=16 B vec4, S=4 B scalar, U=4 B)
 STAGE_BYTES_F32 = {"hash": 16 + 8, "reorder": 8 + 4 * 16 + 2 * 4, "density": 16 + 2 * 4, "forces": 3 * 16 + 2 * 4,
                    "integrate": 5 * 16}
+# a full step on the production kernels runs forces + integrate + next-step hash as ONE launch: its algorithmic
+# bytes are the sum of the three reference stages it implements
+FUSED_FORCES_BYTES_F32 = STAGE_BYTES_F32["forces"] + STAGE_BYTES_F32["integrate"] + STAGE_BYTES_F32["hash"]
+KERNEL_OF_STAGE = {"forces": "k_forces_tiled", "density": "k_density_tiled", "reorder": "k_reorder", "hash": "k_hash",
+                   "integrate": "k_integrate", "sort": "radix_sort_onesweep"}
+
+
+def measured_traffic(stage, n):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC profile (2*FETCH_SIZE + WRITE_SIZE,
+    the gfx950 correction of MI355X_MICROARCH.md), scaled by particle count; None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_b_ns10M_hbm_traffic.json")
+    try:
+        doc = json.load(open(path))
+        k = doc["kernels"][KERNEL_OF_STAGE[stage]]
+        return k["hbm_bytes_per_launch_corrected"] * (n / float(doc["particles"]))
+    except Exception:
+        return None
 
 
 def sesph_bytes_per_particle_step(num_cells, real_bytes=4):
@@ -176,7 +193,8 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
     bpp, passes = sesph_bytes_per_particle_step(num_cells)
-    dom_bytes = STAGE_BYTES_F32.get(dominant, 0) * n
+    fused = dominant == "forces" and not args.reference_order and "integrate" not in warm
+    dom_bytes = (FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)) * n
     dom_avg_ms = dom_ms / max(1, dom_launches)
     achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
     out = {
@@ -204,12 +222,14 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": dominant,
+            "kernel": "forces+integrate+hash (one fused launch)" if fused else dominant,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic(dominant, n),
+            "traffic_source": "profiles/r01_b_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
+                              "scaled by particle count",
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes,

@@ -253,13 +253,14 @@ def bench_main(args, lattice, rank, world, local_rank):
     if int(owned.item()) != n_global or int(ok.item()) != 1:
         raise SystemExit("slab run lost particles or went non-finite: %d of %d" % (int(owned.item()), n_global))
 
-    from bench import HBM_PEAK_GBS, STAGE_BYTES_F32, sesph_bytes_per_particle_step
+    from bench import FUSED_FORCES_BYTES_F32, HBM_PEAK_GBS, STAGE_BYTES_F32, measured_traffic, sesph_bytes_per_particle_step
 
     num_cells = int(p["numCells"][0])
     value = n_global * args.steps / dt
     bpp, passes = sesph_bytes_per_particle_step(num_cells)
     n_local = eng.n_local
-    dom_bytes = STAGE_BYTES_F32.get(dominant, 0) * n_local
+    fused = dominant == "forces" and "integrate" not in warm
+    dom_bytes = (FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)) * n_local
     dom_avg_ms = dom_ms / max(1, dom_launches)
     achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
     out = {
@@ -286,8 +287,9 @@ def bench_main(args, lattice, rank, world, local_rank):
             "message_bytes_per_direction": eng.msg_bytes,
         },
         "roofline": {
-            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_avg_ms": dom_avg_ms,
+            "bound": "hbm", "kernel": "forces+integrate+hash (one fused launch)" if fused else dominant, "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dominant, n_local),
+            "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches, "algorithmic_bytes_per_launch": dom_bytes, "rank": 0,
             "whole_step": {"bytes_per_particle_step": bpp, "radix_passes": passes,
                            "achieved_per_gpu": bpp * value / world / 1e9, "frac_per_gpu": bpp * value / world / 1e9 / HBM_PEAK_GBS},

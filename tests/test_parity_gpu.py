@@ -288,6 +288,59 @@ def test_full_size_c2_properties(hip_lib):
     assert rel_err(a["forces"], o.get("forces")) <= TOL_STAGE
 
 
+def test_full_size_c3_iisph_properties(hip_lib):
+    """BASELINE config C3 (160^3 = 4,096,000 particles, IISPH, fp32): one full step against the oracle on the same
+    inputs (threads on the host cores), plus solver-loop properties."""
+    p = Oracle.default_params(IISPH)
+    sc = scene.dam_break("C3", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    n = len(sc["pos"])
+    assert n == 4_096_000
+    s = capi.Solver(p, n, solver=capi.IISPH)
+    s.set_particles(sc["pos"], sc["vel"])
+    s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    s.step(1)
+    gp, gv, gpr = s.download(pressure=True)
+    assert s.last_iterations >= 2                      # the reference's loop runs at least twice (sph_cuda.cu:741)
+    assert np.isfinite(gp).all() and np.isfinite(gv).all() and (gpr >= 0).all()   # pressures are clamped at 0
+    assert np.all(gp[:, 3] == 1.0) and np.all(gv[:, 3] == 0.0)   # iisph_integrate sets w (sph_kernel_impl.cuh:1653)
+    o = Oracle(p, solver=IISPH, threads=min(16, os.cpu_count() or 1))
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    o.step(1)
+    assert s.last_iterations == o.last_iters
+    np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+    np.testing.assert_array_equal(s.get("index"), o.get("index"))
+    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+    assert rel_err(gpr, o.get("pressure")) <= 10 * TOL_STEPS
+
+
+def test_full_size_c5_fp64_monaghan(hip_lib):
+    """BASELINE config C5 (1,000,000 particles, DOUBLE_PRECISION=1, KERNEL_SET=0): tiled == reference-order bit
+    for bit, and the oracle's density/forces on the same inputs."""
+    p = Oracle.default_params(SESPH, double=True, kernel_set=0)
+    sc = scene.dam_break("C5", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]), real=np.float64)
+    n = len(sc["pos"])
+    res = []
+    for ref in (False, True):
+        s = capi.Solver(p, n, double=True, kernel_set=0, reference_order=ref)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step_partial(capi.STAGE_FORCES)
+        res.append((s.get("hash"), s.get("index"), s.get("dens"), s.get("pres"), s.get("forces")))
+        s.close()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    o = Oracle(p, True, 0, SESPH, threads=min(16, os.cpu_count() or 1))
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    o.step(1, stop=STOP_FORCES)
+    np.testing.assert_array_equal(res[0][0], o.get("hash"))
+    np.testing.assert_array_equal(res[0][1], o.get("index"))
+    assert rel_err(res[0][2], o.get("dens")) <= TOL_STAGE
+    assert rel_err(res[0][4], o.get("forces")) <= TOL_STAGE
+
+
 def test_params_change_and_diagnostics(hip_lib):
     p, pos, vel = default_scene(SESPH)
     o, s = make_pair(p, pos, vel)
