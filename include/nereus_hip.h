@@ -69,6 +69,8 @@ enum {
                                            bit-level comparison with the oracle */
     NRS_FLAG_NO_FUSION = 1u << 2,       /* keep forces, integrate and hash as three launches (default: a full step
                                            on the production kernels fuses them into the force kernel) */
+    NRS_FLAG_NO_SHARED_LISTS = 1u << 3, /* the force kernel re-scans the neighbourhood instead of consuming the hit lists
+                                           the density kernel of the same step found (saves HIT_CAP*4 B/particle of HBM) */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };

@@ -118,6 +118,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     // IISPH
     DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij;
     DevBuf redPartial, redOut;
+    DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
     // slab decomposition
     bool slabOn = false;
     SlabCfg slab = {INT_MIN / 2, INT_MAX / 2, 2};
@@ -150,7 +151,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &ghostPos, &ghostVel, &slabCounts, &slabTotals};
+                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals};
         for (DevBuf *b : all) b->release();
         if (ownStream && stream) (void)hipStreamDestroy(stream);
     }
@@ -196,6 +197,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(diiF.alloc(v)); NRSCHK(diiB.alloc(v)); NRSCHK(sumDij.alloc(v));
             DevBuf *z[] = {&densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP, &diiF, &diiB, &sumDij};
             for (DevBuf *b : z) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, stream));
+        }
+        if (!iisph() && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_SHARED_LISTS))) {
+            NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
+            NRSCHK(hitCounts.alloc((size_t)cap * 4));
         }
         NRSCHK(redPartial.alloc(sizeof(double) * 1024));
         NRSCHK(redOut.alloc(sizeof(double)));
@@ -439,11 +444,15 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const dim3 g(nblocks(N)), b(BLOCK);
         GridView<R> G = grid_view();
         if (slabOn) { G.actLo = slab.lo - 1; G.actHi = slab.hi + 1; } // density is also needed one cell beyond the cuts
+        // the density kernel's hit lists are handed to the force kernel when both run in this call
+        HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
+        const bool share = !refOrder() && hitBuf.p && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         if (refOrder())
             hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         else
-            launch_density_tiled<R, KSET, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+            launch_density_tiled<R, KSET, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(), dens.as<R>(),
+                                                 presB.as<R>(), N);
         if (slabOn) { G.actLo = slab.lo; G.actHi = slab.hi; }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_DENSITY) return NRS_OK;
@@ -459,14 +468,15 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             fo.newPos = posA.as<T4>(); fo.newVel = velA.as<T4>();
             fo.hash = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
             fo.index = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
-            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), velB.as<T4>(), dens.as<R>(),
-                                                      presB.as<R>(), (T4 *)nullptr, &fo, N);
+            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
+                                                      velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
             hashNext = fo.hash; indexNext = fo.index;
             hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
             fusedThisStep = true;
         } else {
-            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, hashCur, posB.as<T4>(), velB.as<T4>(), dens.as<R>(),
-                                                      presB.as<R>(), forces.as<T4>(), (const FusedOut<R> *)nullptr, N);
+            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
+                                                      velB.as<T4>(), dens.as<R>(), presB.as<R>(), forces.as<T4>(),
+                                                      (const FusedOut<R> *)nullptr, N);
         }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_FORCES || fuse) return NRS_OK;

@@ -168,16 +168,19 @@ template <typename R> struct Sweep {
 
 // Merge cursor over the two hit lists: yields hits in the reference's order (cell 0 fluid, cell 0 boundary,
 // cell 1 fluid, ...).  key = 2*cell + kind identifies the partial sum a hit belongs to.
-template <int W> struct HitMerge {
-    uint32_t (*lst)[W];
-    uint32_t tid;
+// The lists are addressed as base[k * stride]: the thread's column of the LDS array (stride = workgroup size) or of
+// the global hit buffer written by the density kernel (stride = particle capacity); both are k-major, so a wave
+// reads/writes 64 consecutive words per k.
+struct HitMerge {
+    const uint32_t *base;
+    uint32_t stride;
     int nf, nb, kf, kb;
-    NRS_DEV HitMerge(uint32_t (*l)[W], uint32_t t, HitCounts hc) : lst(l), tid(t), nf(hc.nf), nb(hc.nb), kf(0), kb(0) {}
+    NRS_DEV HitMerge(const uint32_t *b, uint32_t st, HitCounts hc) : base(b), stride(st), nf(hc.nf), nb(hc.nb), kf(0), kb(0) {}
     NRS_DEV bool next(uint32_t &index, bool &boundary, uint32_t &key)
     {
         if (kf >= nf && kb >= nb) return false;
-        const uint32_t ef = kf < nf ? lst[kf][tid] : 0xffffffffu;
-        const uint32_t eb = kb < nb ? lst[HIT_CAP - 1 - kb][tid] : 0xffffffffu;
+        const uint32_t ef = kf < nf ? base[(uint32_t)kf * stride] : 0xffffffffu;
+        const uint32_t eb = kb < nb ? base[(uint32_t)(HIT_CAP - 1 - kb) * stride] : 0xffffffffu;
         const uint32_t tf = ef >> HIT_TAG_SHIFT, tb = eb >> HIT_TAG_SHIFT;
         boundary = tb < tf; // fluid first inside a cell; the 0xffffffff sentinel has tag 31 > 26
         const uint32_t e = boundary ? eb : ef;
@@ -189,16 +192,16 @@ template <int W> struct HitMerge {
 };
 
 // ---- phase 2 of the density (computeDensityPressure, sph_kernel_impl.cuh:365-433): hits → rho -----------
-template <typename R, int KSET, bool HAS_B, int W>
+template <typename R, int KSET, bool HAS_B>
 NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const typename Vec4T<R>::type *__restrict__ sPos,
-                            V3<R> p, uint32_t (*lst)[W], uint32_t tid, HitCounts hc)
+                            V3<R> p, const uint32_t *lbase, uint32_t lstride, HitCounts hc)
 {
     const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
     R d = (R)0.0;
     d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
     R part = (R)0.0; // the reference adds one partial sum per (cell, fluid|boundary)
     uint32_t prevKey = 0xffffffffu;
-    HitMerge<W> it(lst, tid, hc);
+    HitMerge it(lbase, lstride, hc);
     uint32_t j, key;
     bool isB;
     while (it.next(j, isB, key)) {
@@ -206,8 +209,12 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
         if (HAS_B && isB) {
             const typename Vec4T<R>::type b = G.sB[j];
             const V3<R> r = p - xyz<R>(b);
-            const R psi = rd * b.w;
-            part += (psi * W_dens<R, KSET>(r, ir, kp));
+            // the list may have been built with the wider cut-off of the force loop (shared lists): apply the
+            // density loop's own test (sph_kernel_impl.cuh:347); contributions are unchanged when it was not
+            if (length(r) < ir) {
+                const R psi = rd * b.w;
+                part += (psi * W_dens<R, KSET>(r, ir, kp));
+            }
         } else {
             const V3<R> r = p - xyz<R>(sPos[j]);
             part += (pm * W_dens<R, KSET>(r, ir, kp));
@@ -218,12 +225,12 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
 }
 
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
-template <typename R, int KSET, bool SURF, bool HAS_B, int W>
+template <typename R, int KSET, bool SURF, bool HAS_B>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sPos,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
-                                     uint32_t (*lst)[W], uint32_t tid, HitCounts hc)
+                                     const uint32_t *lbase, uint32_t lstride, HitCounts hc)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -238,7 +245,7 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
     else kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
     const R epsilon = (R)0.01;
     const R beta = P.beta, rd = P.restDensity;
-    HitMerge<W> it(lst, tid, hc);
+    HitMerge it(lbase, lstride, hc);
     uint32_t j, key;
     bool isB;
     while (it.next(j, isB, key)) {
@@ -306,24 +313,51 @@ NRS_DEV uint32_t xcd_tile(uint32_t b, uint32_t nb)
     return (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
 }
 
+// Hit lists shared between the two gathers of a step: the density kernel scans once, uses the hits, and (when
+// `hb.hits` is set) leaves them in global memory for the force kernel, which then needs no scan and no LDS.
+// hits[k * stride + i] is particle i's k-th list slot (k-major ⇒ coalesced), counts[i] = nf | nb << 8 | over << 16.
+struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; };
+NRS_DEV uint32_t pack_counts(HitCounts hc) { return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u); }
+NRS_DEV HitCounts unpack_counts(uint32_t c)
+{
+    HitCounts hc;
+    hc.nf = (int)(c & 0xffu); hc.nb = (int)((c >> 8) & 0xffu); hc.over = ((c >> 16) & 1u) != 0u;
+    return hc;
+}
+
 // ---- density + Tait pressure (computeDensityPressure, sph_kernel_impl.cuh:365-433) -----------------------
-template <typename R, int KSET, bool HAS_B>
+// SHARE: build the lists with the force loop's (wider) boundary cut-off and publish them for the force kernel.
+template <typename R, int KSET, bool HAS_B, bool SHARE>
 __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                          const typename Vec4T<R>::type *__restrict__ sPos,
-                                                         R *__restrict__ dens, R *__restrict__ pres, uint32_t n)
+                                                         R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
+                                                         uint32_t n)
 {
     __shared__ uint32_t lst[HIT_CAP][BLOCK];
     const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t tid = threadIdx.x;
     const V3<R> p = xyz<R>(sPos[i]);
-    if (!slab_active<R>(P, G, p.x)) { dens[i] = (R)0; if (pres) pres[i] = (R)0; return; }
-    const HitCounts hc = Sweep<R>::template scan<HAS_B, 0, BLOCK>(P, G, thr, sPos, i, p, lst);
+    if (!slab_active<R>(P, G, p.x)) {
+        dens[i] = (R)0;
+        if (pres) pres[i] = (R)0;
+        if (SHARE) hb.counts[i] = 0u;
+        return;
+    }
+    constexpr int BF = SHARE ? (KSET == KS_MULLER ? 1 : 2) : 0;
+    const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK>(P, G, thr, sPos, i, p, lst);
     R d;
     if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
-    else d = density_from_hits<R, KSET, HAS_B, BLOCK>(P, G, sPos, p, lst, tid, hc);
+    else d = density_from_hits<R, KSET, HAS_B>(P, G, sPos, p, &lst[0][tid], BLOCK, hc);
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
+    if (SHARE) {
+        hb.counts[i] = pack_counts(hc);
+        if (!hc.over) {
+            for (int k = 0; k < hc.nf; ++k) hb.hits[(size_t)k * hb.stride + i] = lst[k][tid];
+            for (int k = 0; k < hc.nb; ++k) hb.hits[(size_t)(HIT_CAP - 1 - k) * hb.stride + i] = lst[HIT_CAP - 1 - k][tid];
+        }
+    }
 }
 
 // ---- forces (computeForces, sph_kernel_impl.cuh:609-680).  FUSE: the same launch also integrates
@@ -335,6 +369,26 @@ template <typename R> struct FusedOut {
     uint32_t *hash, *index; // next step's keys / values
 };
 
+template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
+NRS_DEV void forces_epilogue(const Params<R> &P, typename Vec4T<R>::type p4, typename Vec4T<R>::type v4, V3<R> f,
+                             typename Vec4T<R>::type *__restrict__ forces, const FusedOut<R> &fo, uint32_t i)
+{
+    if (forces) forces[i] = mk4<R>(f, (R)0);
+    if (FUSE) {
+        const R dt = P.timestep, m1 = P.particleMass;
+        const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
+        const V3<R> accel = dt * f / m1;
+        const V3<R> v = vel1 + accel;
+        const V3<R> pn = pos1 + dt * v;
+        fo.newPos[i] = mk4<R>(pn, p4.w);
+        fo.newVel[i] = mk4<R>(v, v4.w);
+        const I3 g = calcGridPos<R>(P, pn);
+        fo.hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
+        fo.index[i] = i;
+    }
+}
+
+// own scan (used when no shared lists exist: partial steps after nrs_step_partial(DENSITY) etc.)
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
 __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
@@ -358,21 +412,38 @@ __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R>
         const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK>(P, G, thr, sPos, i, pos1, lst);
         ForceAcc<R> A;
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-        else A = forces_from_hits<R, KSET, SURF, HAS_B, BLOCK>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, lst, tid, hc);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, &lst[0][tid], BLOCK, hc);
         f = sesph_total_force<R>(P, A, dens);
     }
-    if (forces) forces[i] = mk4<R>(f, (R)0);
-    if (FUSE) {
-        const R dt = P.timestep, m1 = P.particleMass;
-        const V3<R> accel = dt * f / m1;
-        const V3<R> v = vel1 + accel;
-        const V3<R> pn = pos1 + dt * v;
-        fo.newPos[i] = mk4<R>(pn, p4.w);
-        fo.newVel[i] = mk4<R>(v, v4.w);
-        const I3 g = calcGridPos<R>(P, pn);
-        fo.hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
-        fo.index[i] = i;
+    forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
+}
+
+// scan-free form: consumes the hit lists the density kernel of the same step published (no LDS ⇒ occupancy is
+// bounded by registers only)
+template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
+__global__ __launch_bounds__(BLOCK) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
+                                                        const typename Vec4T<R>::type *__restrict__ sPos,
+                                                        const typename Vec4T<R>::type *__restrict__ sVel,
+                                                        const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                        typename Vec4T<R>::type *__restrict__ forces, FusedOut<R> fo,
+                                                        uint32_t n)
+{
+    typedef typename Vec4T<R>::type T4;
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const T4 p4 = sPos[i];
+    const T4 v4 = sVel[i];
+    const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
+    V3<R> f = mk3<R>(0, 0, 0);
+    if (slab_active<R>(P, G, pos1.x)) {
+        const R dens = sDens[i], pres = sPres[i];
+        const HitCounts hc = unpack_counts(hb.counts[i]);
+        ForceAcc<R> A;
+        if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc);
+        f = sesph_total_force<R>(P, A, dens);
     }
+    forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
 }
 
 static inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
@@ -401,28 +472,37 @@ template <typename R> static inline CutThresholds make_thresholds(const Params<R
 }
 
 template <typename R, int KSET, bool HAS_B>
-static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const uint32_t * /*hashSorted*/,
+static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer *share,
                                         const typename Vec4T<R>::type *sPos, R *dens, R *pres, uint32_t n)
 {
     const CutThresholds thr = make_thresholds<R>(P);
-    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr, sPos,
-                       dens, pres, n);
+    const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
+    HitBuffer hb = {nullptr, nullptr, 0};
+    if (share) {
+        hb = *share;
+        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
+    } else {
+        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
+    }
 }
+// `lists`: hit lists published by launch_density_tiled of the same step (then no scan), or nullptr
 template <typename R, int KSET, bool SURF, bool HAS_B>
-static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const uint32_t * /*hashSorted*/,
+static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer *lists,
                                        const typename Vec4T<R>::type *sPos, const typename Vec4T<R>::type *sVel, const R *dens,
                                        const R *pres, typename Vec4T<R>::type *forces, const FusedOut<R> *fused, uint32_t n)
 {
-    const CutThresholds thr = make_thresholds<R>(P);
     FusedOut<R> fo;
     fo.newPos = fo.newVel = nullptr;
     fo.hash = fo.index = nullptr;
+    if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
-    if (fused) {
-        fo = *fused;
-        hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
+    if (lists) {
+        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
+        else hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
     } else {
-        hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
+        const CutThresholds thr = make_thresholds<R>(P);
+        if (fused) hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
+        else hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);
     }
 }
 
