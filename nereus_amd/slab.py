@@ -194,6 +194,16 @@ def rank_scene(lattice_per_rank, rank, world, params, real=np.float32, spacing=0
     return p, cuts, pos, vel, bi, vb.astype(real), dict(particles=gnx * ny * nz, tank=(tx, ty, tz))
 
 
+def capacities(lattice, h, n_owned, real=np.float32):
+    """(message capacity, context capacity) in particles for a slab of the lattice scene: a 2-cell halo holds
+    about HALO_CELLS * ny * nz * (h/d) lattice particles; 60 % head-room for compression plus migrants."""
+    nx, ny, nz = lattice
+    d = float(real(h)) - 0.005
+    halo_est = int(HALO_CELLS * ny * nz * (h / d))
+    msg_cap = int(1.6 * halo_est) + 8192
+    return msg_cap, int(n_owned * 1.15) + 4 * msg_cap
+
+
 def bench_main(args, lattice, rank, world, local_rank):
     """bench.py body for WORLD_SIZE > 1 (launched by torchrun, one rank per GPU)."""
     import torch
@@ -209,11 +219,7 @@ def bench_main(args, lattice, rank, world, local_rank):
     p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
     t_gen = time.perf_counter() - t_gen
     nx, ny, nz = lattice
-    h = float(p["interactionRadius"][0])
-    d = float(np.float32(h)) - 0.005
-    halo_est = int(HALO_CELLS * ny * nz * (h / d) * 1.0)
-    msg_cap = int(1.6 * halo_est) + 8192
-    cap = int(len(pos) * 1.15) + 4 * msg_cap
+    msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos))
     eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank)
     eng.load(pos, vel, bi, vbi)
     drv = SlabDriver(eng, rank, world)

@@ -112,3 +112,26 @@ def test_slab_protocol_gloo_cpu(tmp_path, world):
 @pytest.mark.gpu
 def test_slab_hip_engine_two_ranks_one_gpu(tmp_path, hip_lib):
     assert _run(2, 25, True, tmp_path) > 0
+
+
+def test_message_capacity_rule_covers_the_halo():
+    """bench.py sizes the fixed message buffers from the lattice; check the rule against real partition counts."""
+    sys.path.insert(0, ROOT)
+    from nereus_amd import slab
+    from nereus_amd.params import default_params
+    from tests.slab_check_engine import OracleSlabEngine
+
+    lattice, world = (24, 20, 18), 3
+    for rank in range(world):
+        p, cuts, pos, vel, bi, vbi, info = slab.rank_scene(lattice, rank, world, default_params(0))
+        msg_cap, cap = slab.capacities(lattice, float(p["interactionRadius"][0]), len(pos))
+        eng = OracleSlabEngine(p, msg_cap, cuts[rank], cuts[rank + 1])
+        eng.load(pos, vel, bi, vbi)
+        left = eng.make_buffer() if rank > 0 else None
+        right = eng.make_buffer() if rank < world - 1 else None
+        stay, ml, hl, mr, hr, gh = eng.pack(left, right)
+        assert stay == len(pos) and ml == mr == gh == 0
+        assert max(hl, hr) * 1.3 <= msg_cap and stay + 2 * max(hl, hr) <= cap
+        if rank > 0:
+            assert hl > 0
+        assert abs(len(pos) - np.prod(lattice)) <= 2 * lattice[1] * lattice[2]  # count-balanced to within two planes
