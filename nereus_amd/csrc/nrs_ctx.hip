@@ -17,6 +17,7 @@
 #include "../../include/nereus_hip.h"
 #include "nrs_kernels_ref.h"
 #include "nrs_kernels_tiled.h"
+#include "nrs_kernels_iisph.h"
 #include "nrs_kernels_slab.h"
 #include <climits>
 
@@ -198,7 +199,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             DevBuf *z[] = {&densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP, &diiF, &diiB, &sumDij};
             for (DevBuf *b : z) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, stream));
         }
-        if (!iisph() && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_SHARED_LISTS))) {
+        // SESPH: density → forces; IISPH (Muller kernels only: the Monaghan support is 2h): one scan feeds the chain
+        if ((!iisph() || KSET == KS_MULLER) && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_SHARED_LISTS))) {
             NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
             NRSCHK(hitCounts.alloc((size_t)cap * 4));
         }
@@ -520,18 +522,30 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const GridView<R> G = grid_view();
         IisphArrays<R> I = iisph_view();
         // predictAdvection (sph_cuda.cu:513-697)
+        // one neighbourhood scan per step: its hit lists drive the rest of the chain (nrs_kernels_iisph.h)
+        const bool lists = !refOrder() && hitBuf.p != nullptr && KSET == KS_MULLER;
+        const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
-        hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), (R *)nullptr, N);
+        if (lists) launch_density_wide<R, KSET, HAS_B>(stream, P, G, hb, posB.as<T4>(), dens.as<R>(), N);
+        else hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), (R *)nullptr, N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_DENSITY) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_DISPLACEMENT));
-        hipLaunchKernelGGL((k_displacement_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
-                           dens.as<R>(), presB.as<R>(), N);
+        if (lists)
+            hipLaunchKernelGGL((k_displacement_lists<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N);
+        else
+            hipLaunchKernelGGL((k_displacement_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_DISPLACEMENT) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_ADVECTION));
-        hipLaunchKernelGGL((k_advection_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
-                           dens.as<R>(), presB.as<R>(), N);
+        if (lists)
+            hipLaunchKernelGGL((k_advection_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N);
+        else
+            hipLaunchKernelGGL((k_advection_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_ADVECTION) return NRS_OK;
         // pressureSolve (sph_cuda.cu:702-899): while ((rho_avg - 1000) > 1 || l < 2)
@@ -541,9 +555,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const R rd = 1000.f;
         const R max_rho_err = 1.f;
         while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
-            hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
-            hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
-                               presB.as<R>(), N);
+            if (lists) hipLaunchKernelGGL((k_sumdij_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), N);
+            else hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
+            if (lists && !HAS_B) // with boundary particles the reference's loop mixes index spaces (Q6): reference-order kernel
+                hipLaunchKernelGGL((k_pressure_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+            else
+                hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
+                                   presB.as<R>(), N);
             std::swap(I.P_l, I.P_l_next);
             std::swap(P_l.p, P_l2.p);
             double acc = 0.0;
@@ -557,7 +575,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_SOLVE) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
-        hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        if (lists && !HAS_B)
+            hipLaunchKernelGGL((k_pforce_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        else
+            hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_PFORCE) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_INTEGRATE));

@@ -1,0 +1,413 @@
+// nrs_kernels_iisph.h — list-driven kernels of the IISPH chain (Muller kernels).
+//
+// The reference runs 6 + 2L neighbourhood sweeps per IISPH step, each re-walking the 27 cells.
+// Here the neighbourhood is scanned ONCE per step (k_density_tiled<..., WIDE>, nrs_kernels_tiled.h): the hit lists
+// it publishes keep the particle itself and every candidate with length(r)^2 <= h^2 — the widest cut-off any loop
+// of the chain implies — tagged with the neighbour-cell number.  The kernels below only walk those lists, applying
+// each reference loop's own exclusions (j != self, j != thread id (Q5), length(r) < h) and forming the sums in the
+// reference's order (per-cell partial sums where the reference has them), so they are bit-identical to the
+// reference-order kernels of nrs_kernels_ref.h.  No LDS, no cell-table traffic.
+//
+// Not list-driven: computePressure / computePressureForce when boundary particles exist (their boundary loops run
+// over an index range that mixes fluid and boundary indices, SURVEY Q6 — replicated by the reference-order kernels),
+// Monaghan kernels (support 2h: no list cut-off is exact), and particles whose list overflowed (per-particle flag:
+// such a block of work falls back to the reference-order routine for that particle).
+#pragma once
+#include "nrs_kernels_tiled.h"
+
+namespace nrs {
+
+// Walk the merged hit lists; f(j, isBoundary, newPartial) with newPartial = first hit of a (cell, kind) group.
+template <typename F> NRS_DEV void for_each_hit(const uint32_t *lbase, uint32_t lstride, HitCounts hc, F &&f)
+{
+    HitMerge it(lbase, lstride, hc);
+    uint32_t j, key, prevKey = 0xffffffffu;
+    bool isB;
+    while (it.next(j, isB, key)) {
+        const bool fresh = key != prevKey;
+        prevKey = key;
+        f(j, isB, fresh);
+    }
+}
+
+// ---- computeDisplacementFactor (sph_kernel_impl.cuh:851-963) -----------------------------------------------
+template <typename R, int KSET, bool SURF, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_displacement_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                              const typename Vec4T<R>::type *__restrict__ sPos,
+                                                              const typename Vec4T<R>::type *__restrict__ sVel,
+                                                              const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                              uint32_t n)
+{
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const V3<R> vel1 = xyz<R>(sVel[i]);
+    const R pres = (R)0.0;
+    const R dens = sDens[i];
+    const R kpg = P.kpoly_grad, pm = P.particleMass, ir = P.interactionRadius, rd = P.restDensity, dt = P.timestep;
+    const HitCounts hc = unpack_counts(hb.counts[i]);
+    ForceAcc<R> A;
+    V3<R> df = mk3<R>(0, 0, 0), db = mk3<R>(0, 0, 0);
+    if (hc.over) {
+        A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
+    } else {
+        A = forces_from_hits<R, KSET, SURF, HAS_B, true>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc, i);
+    }
+    V3<R> fvisc = 2.0 * A.fvisc;
+    fvisc = (pm * P.viscosity) * fvisc;
+    const V3<R> fgrav = pm * mk3<R>(P.gravity[0], P.gravity[1], P.gravity[2]);
+    const V3<R> force_adv = fvisc + A.fsurf + A.fbound + fgrav;
+    const V3<R> vel_adv = vel1 + dt * (force_adv / pm);
+    I.forcesAdv[i] = mk4<R>(force_adv, (R)0.0);
+    I.velAdv[i] = mk4<R>(vel_adv, (R)0.0);
+    if (hc.over) { // per-cell walk of the reference-order kernel for this particle
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    V3<R> res = mk3<R>(0, 0, 0);
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            if (length(d) < ir) res = res - ((pm / (dens * dens)) * W_grad<R, KSET>(d, ir, kpg));
+                        }
+                    }
+                    df = df + res;
+                    if (HAS_B) {
+                        V3<R> rb = mk3<R>(0, 0, 0);
+                        const uint32_t sb = G.bCellStart[h];
+                        if (sb != CELL_EMPTY) {
+                            const uint32_t e = G.bCellEnd[h];
+                            for (uint32_t j = sb; j < e; ++j) {
+                                const typename Vec4T<R>::type b = G.sB[j];
+                                const V3<R> d = pos1 - xyz<R>(b);
+                                if (length(d) < ir) rb = rb - (((rd * b.w) / (dens * dens)) * W_grad<R, KSET>(d, ir, kpg));
+                            }
+                        }
+                        db = db + rb;
+                    }
+                }
+    } else {
+        V3<R> part = mk3<R>(0, 0, 0);
+        bool partB = false;
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool isB, bool fresh) {
+            if (fresh) {
+                if (partB) db = db + part; else df = df + part;
+                part = mk3<R>(0, 0, 0);
+                partB = isB;
+            }
+            if (HAS_B && isB) {
+                const typename Vec4T<R>::type b = G.sB[j];
+                const V3<R> d = pos1 - xyz<R>(b);
+                const R psi = rd * b.w;
+                if (length(d) < ir) part = part - ((psi / (dens * dens)) * W_grad<R, KSET>(d, ir, kpg));
+            } else if (j != i) {
+                const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                if (length(d) < ir) part = part - ((pm / (dens * dens)) * W_grad<R, KSET>(d, ir, kpg));
+            }
+        });
+        if (partB) db = db + part; else df = df + part;
+    }
+    I.diiF[i] = mk4<R>(df, (R)0.0);
+    I.diiB[i] = mk4<R>(db, (R)0.0);
+}
+
+// ---- computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) --------------------------------------------------
+template <typename R, int KSET, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_advection_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                           const typename Vec4T<R>::type *__restrict__ sPos,
+                                                           const typename Vec4T<R>::type *__restrict__ sVel,
+                                                           const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                           uint32_t n)
+{
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const V3<R> vel1 = xyz<R>(sVel[i]);
+    const V3<R> velAdv1 = xyz<R>(I.velAdv[i]);
+    const R dens = sDens[i];
+    const V3<R> diif = xyz<R>(I.diiF[i]);
+    const V3<R> diib = xyz<R>(I.diiB[i]);
+    const R kpg = P.kpoly_grad, pm = P.particleMass, ir = P.interactionRadius, rd = P.restDensity, dt = P.timestep;
+    const HitCounts hc = unpack_counts(hb.counts[i]);
+    R rho_advf = (R)0.0, rho_advb = (R)0.0, aii = (R)0.0;
+    if (hc.over) {
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    R res = (R)0.0;
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> v1v2 = velAdv1 - xyz<R>(I.velAdv[j]);
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            if (length(d) < ir) res += (dt * pm * dot(v1v2, W_grad<R, KSET>(d, ir, kpg)));
+                        }
+                    }
+                    rho_advf += res;
+                    if (HAS_B) {
+                        R rb = (R)0.0;
+                        const uint32_t sb = G.bCellStart[h];
+                        if (sb != CELL_EMPTY) {
+                            const uint32_t e = G.bCellEnd[h];
+                            for (uint32_t j = sb; j < e; ++j) {
+                                const typename Vec4T<R>::type b = G.sB[j];
+                                const V3<R> d = pos1 - xyz<R>(b);
+                                rb += (dt * (rd * b.w) * dot(vel1, W_grad<R, KSET>(d, ir, kpg)));
+                            }
+                        }
+                        rho_advb += rb;
+                    }
+                }
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    R res = (R)0.0;
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            const R dpi = (pm) / (dens * dens);
+                            const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                            const V3<R> dji = dpi * grad;
+                            res += (pm * dot((diif + diib) - dji, grad));
+                        }
+                    }
+                    aii += res;
+                    if (HAS_B) {
+                        R rb = (R)0.0;
+                        const uint32_t sb = G.bCellStart[h];
+                        if (sb != CELL_EMPTY) {
+                            const uint32_t e = G.bCellEnd[h];
+                            for (uint32_t j = sb; j < e; ++j) {
+                                const typename Vec4T<R>::type b = G.sB[j];
+                                const V3<R> d = pos1 - xyz<R>(b);
+                                const R psi = rd * b.w;
+                                const R dpi = (pm) / (dens * dens);
+                                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                                const V3<R> dji = dpi * grad;
+                                rb += psi * dot((diif + diib) - dji, grad);
+                            }
+                        }
+                        aii += rb;
+                    }
+                }
+    } else {
+        // rho_adv: fluid partials go to rho_advf, boundary partials to rho_advb, one partial per cell
+        R part = (R)0.0;
+        bool partB = false;
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool isB, bool fresh) {
+            if (fresh) {
+                if (partB) rho_advb += part; else rho_advf += part;
+                part = (R)0.0;
+                partB = isB;
+            }
+            if (HAS_B && isB) {
+                const typename Vec4T<R>::type b = G.sB[j];
+                const V3<R> d = pos1 - xyz<R>(b);
+                const R psi = (rd * b.w);
+                part += (dt * psi * dot(vel1, W_grad<R, KSET>(d, ir, kpg)));
+            } else if (j != i) {
+                const V3<R> v1v2 = velAdv1 - xyz<R>(I.velAdv[j]);
+                const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                if (length(d) < ir) part += (dt * pm * dot(v1v2, W_grad<R, KSET>(d, ir, kpg)));
+            }
+        });
+        if (partB) rho_advb += part; else rho_advf += part;
+        // a_ii: every (cell, kind) partial is added to the same accumulator
+        R pa = (R)0.0;
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool isB, bool fresh) {
+            if (fresh) { aii += pa; pa = (R)0.0; }
+            const R dpi = (pm) / (dens * dens);
+            if (HAS_B && isB) {
+                const typename Vec4T<R>::type b = G.sB[j];
+                const V3<R> d = pos1 - xyz<R>(b);
+                const R psi = rd * b.w;
+                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                const V3<R> dji = dpi * grad;
+                pa += psi * dot((diif + diib) - dji, grad);
+            } else if (j != i) {
+                const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+                const V3<R> dji = dpi * grad;
+                pa += (pm * dot((diif + diib) - dji, grad));
+            }
+        });
+        aii += pa;
+    }
+    const R rho_adv = dens + (rho_advf + rho_advb);
+    I.densAdv[i] = rho_adv;
+    I.P_l[i] = (R)(0.5 * sPres[i]);
+    I.aii[i] = aii;
+}
+
+// ---- computeSumDijPj (sph_kernel_impl.cuh:1259-1325): fluid neighbours only -----------------------------------
+template <typename R, int KSET>
+__global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                        const typename Vec4T<R>::type *__restrict__ sPos,
+                                                        const R *__restrict__ sDens, uint32_t n)
+{
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad;
+    HitCounts hc = unpack_counts(hb.counts[i]);
+    V3<R> dijpj = mk3<R>(0, 0, 0);
+    if (hc.over) {
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    V3<R> res = mk3<R>(0, 0, 0);
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j) {
+                            if (j == i) continue;
+                            const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                            const R densj = sDens[j];
+                            res = res - ((pm / (densj * densj)) * I.P_l[j] * W_grad<R, KSET>(d, ir, kpg));
+                        }
+                    }
+                    dijpj = dijpj + res;
+                }
+    } else {
+        hc.nb = 0; // boundary hits play no part here
+        V3<R> part = mk3<R>(0, 0, 0);
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool fresh) {
+            if (fresh) { dijpj = dijpj + part; part = mk3<R>(0, 0, 0); }
+            if (j != i) {
+                const V3<R> d = pos1 - xyz<R>(sPos[j]);
+                const R p_lj = I.P_l[j];
+                const R densj = sDens[j];
+                part = part - ((pm / (densj * densj)) * p_lj * W_grad<R, KSET>(d, ir, kpg));
+            }
+        });
+        dijpj = dijpj + part;
+    }
+    I.sumDij[i] = mk4<R>(dijpj, (R)0.0);
+}
+
+// ---- computePressure without boundary particles (sph_kernel_impl.cuh:1330-1492; Q5: skips j == inv[i], keeps self;
+//      Q7: reads P_l, writes P_l_next) ----------------------------------------------------------------------------
+template <typename R, int KSET>
+__global__ __launch_bounds__(BLOCK) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                          const typename Vec4T<R>::type *__restrict__ sPos,
+                                                          const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n)
+{
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t skip = I.inv[i];
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const R dens = sDens[i];
+    R p_l = I.P_l[i];
+    const R previous_p_l = p_l;
+    const R rho_adv = I.densAdv[i];
+    const R aii = I.aii[i];
+    const V3<R> dijpj = xyz<R>(I.sumDij[i]);
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad, dt = P.timestep, rd = P.restDensity;
+    R fsum = (R)0.0;
+    const R bsum = (R)0.0;
+    const R dpi = pm / (dens * dens);
+    HitCounts hc = unpack_counts(hb.counts[i]);
+    auto term = [&](uint32_t j) {
+        const V3<R> d = pos1 - xyz<R>(sPos[j]);
+        const R p_lj = I.P_l[j];
+        const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+        const V3<R> dji = dpi * (grad);
+        const V3<R> d_ji_pi = dji * p_lj;
+        const V3<R> diifj = xyz<R>(I.diiF[j]);
+        const V3<R> diibj = xyz<R>(I.diiB[j]);
+        const V3<R> sum_dijj = xyz<R>(I.sumDij[j]);
+        fsum += pm * dot(dijpj - (diifj + diibj) * p_lj - (sum_dijj - d_ji_pi), grad);
+    };
+    if (hc.over) {
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j)
+                            if (j != skip) term(j);
+                    }
+                }
+    } else {
+        hc.nb = 0;
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
+    }
+    const R omega = (R)0.5;
+    R rho_corr = rho_adv + fsum + bsum;
+    const R dt2 = dt * dt;
+    const R denom = aii * dt2;
+    const R b = rd - rho_adv;
+    if (fabs(denom) > 1.1920928955078125e-07f /* FLT_EPSILON */)
+        p_l = (R)((1.0 - omega) * previous_p_l + (omega / denom) * (b - dt2 * (bsum + fsum)));
+    else
+        p_l = (R)0.0;
+    const R p = (R)fmax((double)p_l, 0.0);
+    p_l = p;
+    rho_corr += aii * previous_p_l;
+    I.P_l_next[i] = p_l;
+    sPres[i] = p_l;
+    I.densCorr[i] = rho_corr;
+}
+
+// ---- computePressureForce without boundary particles (sph_kernel_impl.cuh:1497-1620, same Q5) ----------------------
+template <typename R, int KSET>
+__global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                        const typename Vec4T<R>::type *__restrict__ sPos,
+                                                        const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t n)
+{
+    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t skip = I.inv[i];
+    const V3<R> pos1 = xyz<R>(sPos[i]);
+    const R p = sPres[i];
+    const R dens = sDens[i];
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad;
+    V3<R> fp = mk3<R>(0, 0, 0);
+    HitCounts hc = unpack_counts(hb.counts[i]);
+    auto term = [&](uint32_t j) {
+        const V3<R> d = pos1 - xyz<R>(sPos[j]);
+        const R pj = sPres[j];
+        const R densj = sDens[j];
+        const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
+        const V3<R> contrib = -pm * pm * (p / (dens * dens) + pj / (densj * densj)) * grad;
+        fp = fp + contrib;
+    };
+    if (hc.over) {
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    const uint32_t s = G.cellStart[h];
+                    if (s != CELL_EMPTY) {
+                        const uint32_t e = G.cellEnd[h];
+                        for (uint32_t j = s; j < e; ++j)
+                            if (j != skip) term(j);
+                    }
+                }
+    } else {
+        hc.nb = 0;
+        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
+    }
+    I.forcesP[i] = mk4<R>(fp, (R)0.0);
+}
+
+} // namespace nrs

@@ -60,7 +60,10 @@ template <typename R> struct Sweep {
     // together; the three x-cells of a row are ONE run [lo,hi) of the sorted array; candidate positions are
     // fetched SCAN_BATCH at a time and tested branch-free; only the (rare) hit takes a branch.  Boundary cells
     // are swept afterwards, only by the lanes that have any, so the fluid sweep stays uniform across the wave.
-    template <bool HAS_B, int BFILT, int W>
+    // FWIDE: fluid candidates are kept up to r2LeH2 instead of lenLtIr (IISPH: several of its loops have no explicit
+    // cut-off and rely on the kernel gradient being 0 beyond h); pass self = 0xffffffff to keep the
+    // particle itself in the list (two IISPH kernels do not exclude it).
+    template <bool HAS_B, int BFILT, int W, bool FWIDE = false>
     static NRS_DEV HitCounts scan(const Params<R> &P, const GridView<R> &G, const CutThresholds thr,
                                   const T4 *__restrict__ sPos, uint32_t self, V3<R> p, uint32_t (*lst)[W])
     {
@@ -69,7 +72,7 @@ template <typename R> struct Sweep {
         const uint32_t cx = (uint32_t)gp.x & mx;
         const uint32_t x0 = (cx - 1u) & mx, x2 = (cx + 1u) & mx;
         const bool contiguous = (cx >= 1u) && (cx + 1u <= mx);
-        const float tF = thr.lenLtIr;
+        const float tF = FWIDE ? thr.r2LeH2 : thr.lenLtIr;
         const float tB = BFILT == 2 ? INFINITY : (BFILT == 1 ? thr.r2LeH2 : thr.lenLtIr);
         const uint32_t tid = threadIdx.x;
         int nf = 0, nb = 0;
@@ -192,9 +195,11 @@ struct HitMerge {
 };
 
 // ---- phase 2 of the density (computeDensityPressure, sph_kernel_impl.cuh:365-433): hits → rho -----------
-template <typename R, int KSET, bool HAS_B>
+// STRICT: the list is the wide IISPH one (self included, fluid kept up to r2LeH2): apply the density loop's own
+// `j != self` and `length < h` tests (sph_kernel_impl.cuh:305-309).
+template <typename R, int KSET, bool HAS_B, bool STRICT = false>
 NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const typename Vec4T<R>::type *__restrict__ sPos,
-                            V3<R> p, const uint32_t *lbase, uint32_t lstride, HitCounts hc)
+                            V3<R> p, const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu)
 {
     const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
     R d = (R)0.0;
@@ -217,7 +222,7 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
             }
         } else {
             const V3<R> r = p - xyz<R>(sPos[j]);
-            part += (pm * W_dens<R, KSET>(r, ir, kp));
+            if (!STRICT || ((j != self) && (length(r) < ir))) part += (pm * W_dens<R, KSET>(r, ir, kp));
         }
     }
     d += part;
@@ -225,12 +230,12 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
 }
 
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
-template <typename R, int KSET, bool SURF, bool HAS_B>
+template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sPos,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
-                                     const uint32_t *lbase, uint32_t lstride, HitCounts hc)
+                                     const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -272,6 +277,7 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
             A.fvisc = A.fvisc - (pm * psi * Pij * grad);
         } else {
             const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
+            if (STRICT && ((j == self) || !(length(p1p2) < ir))) continue; // the loop's own tests (:494,:505)
             const R dens2 = sDens[j];
             const R pres2 = sPres[j];
             const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
@@ -327,7 +333,9 @@ NRS_DEV HitCounts unpack_counts(uint32_t c)
 
 // ---- density + Tait pressure (computeDensityPressure, sph_kernel_impl.cuh:365-433) -----------------------
 // SHARE: build the lists with the force loop's (wider) boundary cut-off and publish them for the force kernel.
-template <typename R, int KSET, bool HAS_B, bool SHARE>
+// WIDE (IISPH, Muller kernels): the published lists keep self and every candidate up to r2LeH2, for the six other
+// kernels of the IISPH chain; the density itself applies its own tests while summing.
+template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                          const typename Vec4T<R>::type *__restrict__ sPos,
                                                          R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
@@ -345,10 +353,10 @@ __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R
         return;
     }
     constexpr int BF = SHARE ? (KSET == KS_MULLER ? 1 : 2) : 0;
-    const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK>(P, G, thr, sPos, i, p, lst);
+    const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK, WIDE>(P, G, thr, sPos, WIDE ? 0xffffffffu : i, p, lst);
     R d;
     if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
-    else d = density_from_hits<R, KSET, HAS_B>(P, G, sPos, p, &lst[0][tid], BLOCK, hc);
+    else d = density_from_hits<R, KSET, HAS_B, WIDE>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
     if (SHARE) {
@@ -484,6 +492,14 @@ static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, 
     } else {
         hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
     }
+}
+template <typename R, int KSET, bool HAS_B>
+static inline void launch_density_wide(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer &hb,
+                                       const typename Vec4T<R>::type *sPos, R *dens, uint32_t n)
+{
+    const CutThresholds thr = make_thresholds<R>(P);
+    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true, true>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr,
+                       sPos, dens, (R *)nullptr, hb, n);
 }
 // `lists`: hit lists published by launch_density_tiled of the same step (then no scan), or nullptr
 template <typename R, int KSET, bool SURF, bool HAS_B>

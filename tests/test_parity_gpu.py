@@ -221,6 +221,41 @@ def test_iisph_stages_and_steps(hip_lib):
     assert rel_err(gp[:, :3], g["pos5"][:, :3]) <= TOL_STEPS
 
 
+def test_iisph_list_kernels_equal_reference_order_bitwise(hip_lib):
+    """The list-driven IISPH chain (one scan per step) against the plain reference-order kernels, bit for bit:
+    no boundaries, with boundaries, and a crowded blob whose hit lists overflow (per-particle fallback)."""
+    scenes = []
+    p, pos, vel = compressed_block()
+    scenes.append((p, pos, vel, None, None))
+    p2, sc = small_dam_break(solver=IISPH)
+    scenes.append((p2, sc["pos"], sc["vel"], sc["bi"], sc["vbi"]))
+    rng = np.random.default_rng(5)
+    h = float(p["interactionRadius"][0])
+    blob = np.ones((120, 4), np.float32)
+    blob[:, :3] = (np.array([0.2, 0.1, -0.3]) + rng.uniform(-0.45 * h, 0.45 * h, (120, 3))).astype(np.float32)
+    loose = np.ones((200, 4), np.float32)
+    loose[:, :3] = (np.array([0.2, 0.1, -0.3]) + rng.uniform(-3 * h, 3 * h, (200, 3))).astype(np.float32)
+    crowd = np.concatenate([blob, loose])
+    scenes.append((p, crowd, np.zeros_like(crowd), None, None))
+    names = ["dens", "velAdv", "forcesAdv", "diiFluid", "diiBoundary", "densAdv", "aii", "sumDij", "densCorr", "P_l", "pres",
+             "forcesP"]
+    for (pp, pos, vel, bi, vbi) in scenes:
+        outs = []
+        for ref in (False, True):
+            s = capi.Solver(pp, len(pos), solver=capi.IISPH, reference_order=ref)
+            s.set_particles(pos, vel)
+            s.set_boundaries(bi, vbi, update_grid=True)
+            s.step_partial(capi.STAGE_I_PFORCE)
+            got = [s.get(nm) for nm in names] + [np.array([s.last_iterations])]
+            s.set_particles(pos, vel)
+            s.step(3)
+            got += list(s.download(pressure=True))
+            outs.append(got)
+            s.close()
+        for nm, a, b in zip(names + ["iters", "pos", "vel", "pressure"], *outs):
+            np.testing.assert_array_equal(a, b, err_msg=nm)
+
+
 def test_iisph_with_boundaries(hip_lib):
     p, sc = small_dam_break(solver=IISPH)
     o, s = make_pair(p, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], solver=IISPH)
