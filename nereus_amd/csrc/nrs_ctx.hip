@@ -557,8 +557,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
             if (lists) hipLaunchKernelGGL((k_sumdij_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), N);
             else hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
-            if (lists && !HAS_B) // with boundary particles the reference's loop mixes index spaces (Q6): reference-order kernel
-                hipLaunchKernelGGL((k_pressure_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+            if (lists)
+                hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
             else
                 hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
                                    presB.as<R>(), N);
@@ -575,8 +575,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_SOLVE) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
-        if (lists && !HAS_B)
-            hipLaunchKernelGGL((k_pforce_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        if (lists)
+            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         else
             hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());

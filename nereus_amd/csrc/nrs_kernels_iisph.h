@@ -8,10 +8,10 @@
 // reference's order (per-cell partial sums where the reference has them), so they are bit-identical to the
 // reference-order kernels of nrs_kernels_ref.h.  No LDS, no cell-table traffic.
 //
-// Not list-driven: computePressure / computePressureForce when boundary particles exist (their boundary loops run
-// over an index range that mixes fluid and boundary indices, SURVEY Q6 — replicated by the reference-order kernels),
-// Monaghan kernels (support 2h: no list cut-off is exact), and particles whose list overflowed (per-particle flag:
-// such a block of work falls back to the reference-order routine for that particle).
+// The boundary loops of computePressure / computePressureForce run over an index range that mixes fluid and boundary
+// indices; they are kept as cell walks with the reference's bounds, next to the list-driven fluid part.
+// Not list-driven: Monaghan kernels (support 2h: no list cut-off is exact) and particles whose list overflowed
+// (per-particle flag: the reference-order cell walk is used for that particle).
 #pragma once
 #include "nrs_kernels_tiled.h"
 
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R>
 
 // ---- computePressure without boundary particles (sph_kernel_impl.cuh:1330-1492; Q5: skips j == inv[i], keeps self;
 //      Q7: reads P_l, writes P_l_next) ----------------------------------------------------------------------------
-template <typename R, int KSET>
+template <typename R, int KSET, bool HAS_B>
 __global__ __launch_bounds__(BLOCK) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
                                                           const typename Vec4T<R>::type *__restrict__ sPos,
                                                           const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n)
@@ -319,9 +319,28 @@ __global__ __launch_bounds__(BLOCK) void k_pressure_lists(Params<R> P, GridView<
     const V3<R> dijpj = xyz<R>(I.sumDij[i]);
     const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad, dt = P.timestep, rd = P.restDensity;
     R fsum = (R)0.0;
-    const R bsum = (R)0.0;
+    R bsum = (R)0.0;
     const R dpi = pm / (dens * dens);
     HitCounts hc = unpack_counts(hb.counts[i]);
+    if (HAS_B) {
+        // boundary part: its own accumulator, so it can run apart from the fluid part.  The loop bounds are the
+        // reference's: from the FLUID cell start to the BOUNDARY cell end, over the boundary array.
+        const I3 gp = calcGridPos<R>(P, pos1);
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                    if (G.bCellStart[h] != CELL_EMPTY) {
+                        const uint32_t s = G.cellStart[h], eB = G.bCellEnd[h];
+                        for (uint32_t j = s; j < eB; ++j) {
+                            const typename Vec4T<R>::type b = G.sB[j];
+                            const V3<R> d = pos1 - xyz<R>(b);
+                            const R psi = rd * b.w;
+                            bsum += psi * dot(dijpj, W_grad<R, KSET>(d, ir, kpg));
+                        }
+                    }
+                }
+    }
     auto term = [&](uint32_t j) {
         const V3<R> d = pos1 - xyz<R>(sPos[j]);
         const R p_lj = I.P_l[j];
@@ -367,8 +386,9 @@ __global__ __launch_bounds__(BLOCK) void k_pressure_lists(Params<R> P, GridView<
     I.densCorr[i] = rho_corr;
 }
 
-// ---- computePressureForce without boundary particles (sph_kernel_impl.cuh:1497-1620, same Q5) ----------------------
-template <typename R, int KSET>
+// ---- computePressureForce (sph_kernel_impl.cuh:1497-1620, same Q5/Q6).  One accumulator takes the fluid terms of a
+//      cell and then that cell's boundary terms, so with boundary particles the list is consumed cell by cell ------
+template <typename R, int KSET, bool HAS_B>
 __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t n)
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R>
     const V3<R> pos1 = xyz<R>(sPos[i]);
     const R p = sPres[i];
     const R dens = sDens[i];
-    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad;
+    const R ir = P.interactionRadius, pm = P.particleMass, kpg = P.kpoly_grad, rd = P.restDensity;
     V3<R> fp = mk3<R>(0, 0, 0);
     HitCounts hc = unpack_counts(hb.counts[i]);
     auto term = [&](uint32_t j) {
@@ -390,22 +410,42 @@ __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R>
         const V3<R> contrib = -pm * pm * (p / (dens * dens) + pj / (densj * densj)) * grad;
         fp = fp + contrib;
     };
-    if (hc.over) {
-        const I3 gp = calcGridPos<R>(P, pos1);
-        for (int z = -1; z <= 1; z++)
-            for (int y = -1; y <= 1; y++)
-                for (int x = -1; x <= 1; x++) {
-                    const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
-                    const uint32_t s = G.cellStart[h];
-                    if (s != CELL_EMPTY) {
-                        const uint32_t e = G.cellEnd[h];
-                        for (uint32_t j = s; j < e; ++j)
-                            if (j != skip) term(j);
-                    }
-                }
-    } else {
+    if (!HAS_B && !hc.over) {
         hc.nb = 0;
         for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
+    } else {
+        const I3 gp = calcGridPos<R>(P, pos1);
+        int kf = 0; // cursor into the fluid list (ascending cell number)
+        for (int c = 0; c < 27; ++c) {
+            const int z = c / 9 - 1, y = (c / 3) % 3 - 1, x = c % 3 - 1;
+            const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+            if (hc.over) {
+                const uint32_t s = G.cellStart[h];
+                if (s != CELL_EMPTY) {
+                    const uint32_t e = G.cellEnd[h];
+                    for (uint32_t j = s; j < e; ++j)
+                        if (j != skip) term(j);
+                }
+            } else {
+                while (kf < hc.nf) {
+                    const uint32_t ent = hb.hits[(size_t)kf * hb.stride + i];
+                    if ((ent >> HIT_TAG_SHIFT) != (uint32_t)c) break;
+                    const uint32_t j = ent & HIT_INDEX;
+                    if (j != skip) term(j);
+                    ++kf;
+                }
+            }
+            if (HAS_B && G.bCellStart[h] != CELL_EMPTY) {
+                const uint32_t s = G.cellStart[h], eB = G.bCellEnd[h];
+                for (uint32_t j = s; j < eB; ++j) { // Q6 bounds
+                    const typename Vec4T<R>::type b = G.sB[j];
+                    const V3<R> d = pos1 - xyz<R>(b);
+                    const R psi = rd * b.w;
+                    const V3<R> contrib = (pm * psi * (p / (dens * dens)) * W_grad<R, KSET>(d, ir, kpg));
+                    fp = fp + contrib;
+                }
+            }
+        }
     }
     I.forcesP[i] = mk4<R>(fp, (R)0.0);
 }

@@ -6,10 +6,11 @@ from nereus_amd import capi, scene
 from nereus_amd.params import default_params
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-p = default_params(0)
+SOLVER = 1 if os.environ.get("IISPH") else 0
+p = default_params(SOLVER)
 lat = scene.CONFIGS[cfg] if cfg in scene.CONFIGS else tuple(int(v) for v in cfg.split(","))
 sc = scene.dam_break(lat, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
-s = capi.Solver(p, len(sc["pos"]), reference_order=bool(os.environ.get("REF")))
+s = capi.Solver(p, len(sc["pos"]), solver=SOLVER, reference_order=bool(os.environ.get("REF")))
 s.set_particles(sc["pos"], sc["vel"]); s.set_boundaries(sc["bi"], sc["vbi"], True)
 s.step(5); s.set_profiling(True); s.step(steps); s.synchronize()
 t = s.stage_ms()
