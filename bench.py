@@ -32,11 +32,35 @@ HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 meas
 # algorithmic bytes per particle per launch of each stage (V=16 B vec4, S=4 B scalar, U=4 B)
 STAGE_BYTES_F32 = {"hash": 16 + 8, "reorder": 8 + 4 * 16 + 2 * 4, "density": 16 + 2 * 4, "forces": 3 * 16 + 2 * 4,
                    "integrate": 5 * 16}
+# IISPH stages: density V+S, displacement 6V+S, advection 5V+5S, per solver iteration sumDij 2V+2S +
+# pressure 4V+7S + reduce S (= 136 B, times L iterations per step), pressure force 2V+2S, integrate 5V
+IISPH_STAGE_BYTES_F32 = {"i_density": 20, "i_displacement": 100, "i_advection": 100, "i_solve": 136, "i_pforce": 40,
+                         "i_integrate": 80}
 # a full step on the production kernels runs forces + integrate + next-step hash as ONE launch: its algorithmic
 # bytes are the sum of the three reference stages it implements
 FUSED_FORCES_BYTES_F32 = STAGE_BYTES_F32["forces"] + STAGE_BYTES_F32["integrate"] + STAGE_BYTES_F32["hash"]
 KERNEL_OF_STAGE = {"forces": "k_forces_lists", "density": "k_density_tiled", "reorder": "k_reorder", "hash": "k_hash",
                    "integrate": "k_integrate", "sort": "radix_sort_onesweep"}
+
+
+def per_stage_roofline(warm, n, num_cells, production):
+    out = {}
+    fused = production and "integrate" not in warm
+    bits = max(1, int(np.ceil(np.log2(max(2, num_cells)))))
+    for name, (ms, launches) in warm.items():
+        if not launches or ms <= 0:
+            continue
+        if name == "sort":
+            bpp = 16 * ((bits + 7) // 8) + 4
+        elif name == "forces" and fused:
+            bpp = FUSED_FORCES_BYTES_F32
+        else:
+            bpp = STAGE_BYTES_F32.get(name)
+        if bpp is None:
+            continue
+        gbs = bpp * n / (ms / launches * 1e-3) / 1e9
+        out[name] = {"ms": ms / launches, "algorithmic_bytes_per_particle": bpp, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+    return out
 
 
 def measured_traffic(stage, n):
@@ -117,6 +141,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="NS", help="scene lattice: NS (216^3), C2 (100^3), C4, C1 ... or nx,ny,nz")
+    ap.add_argument("--solver", default="sesph", choices=["sesph", "iisph"],
+                    help="sesph = the BASELINE metric (default); iisph = config 3 style run of the IISPH chain (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
     args = ap.parse_args()
@@ -155,13 +181,15 @@ def main():
     # ---------------------------------------------------------------- single GPU
     from nereus_amd.params import default_params
 
-    p = default_params(0)  # SPH::SPH() constructor defaults (sph/sph.cpp:29-93)
+    iisph = args.solver == "iisph"
+    p = default_params(1 if iisph else 0)  # constructor defaults (sph/sph.cpp:29-93, iisph/iisph.cpp:28-87)
     t_gen = time.perf_counter()
     sc = scene.dam_break(lattice, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
     t_gen = time.perf_counter() - t_gen
     n = len(sc["pos"])
     stream = torch.cuda.current_stream().cuda_stream
-    s = capi.Solver(p, n, solver=capi.SESPH, device=local_rank, stream=stream, reference_order=args.reference_order)
+    s = capi.Solver(p, n, solver=capi.IISPH if iisph else capi.SESPH, device=local_rank, stream=stream,
+                    reference_order=args.reference_order)
     s.set_particles(sc["pos"], sc["vel"])
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     P = s.params
@@ -193,12 +221,18 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
     bpp, passes = sesph_bytes_per_particle_step(num_cells)
+    if iisph:  # 448 + 16 P + 136 L bytes per particle-step, L = solver iterations of the last step
+        bpp = 448 + 16 * passes + 136 * s.last_iterations
     fused = dominant == "forces" and not args.reference_order and "integrate" not in warm
-    dom_bytes = (FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)) * n
+    if dominant in IISPH_STAGE_BYTES_F32:
+        dom_bpp = IISPH_STAGE_BYTES_F32[dominant] * (s.last_iterations if dominant == "i_solve" else 1)
+    else:
+        dom_bpp = FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)
+    dom_bytes = dom_bpp * n
     dom_avg_ms = dom_ms / max(1, dom_launches)
     achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
     out = {
-        "metric": "particle-steps/sec, SESPH dam-break",
+        "metric": "particle-steps/sec, %s dam-break" % ("IISPH" if iisph else "SESPH"),
         "value": value,
         "unit": "particle-steps/s",
         "n_gpus": 1,
@@ -211,8 +245,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "SESPH dam-break %dx%dx%d = %d particles (+%d tank boundary particles), fp32, Muller kernels, "
-                        "grid %dx%dx%d" % (lattice + (n, len(sc["bi"])) + tuple(int(v) for v in P["gridSize"][0])),
+            "workload": "%s dam-break %dx%dx%d = %d particles (+%d tank boundary particles), fp32, Muller kernels, "
+                        "grid %dx%dx%d" % (("IISPH" if iisph else "SESPH",) + lattice + (n, len(sc["bi"]))
+                                           + tuple(int(v) for v in P["gridSize"][0])),
             "particles": n,
             "boundary_particles": int(len(sc["bi"])),
             "num_cells": num_cells,
@@ -241,9 +276,14 @@ def main():
             },
         },
         "stage_ms_warmup_avg": {k: v[0] / max(1, v[1]) for k, v in warm.items()},
+        # every stage against the same roofline (algorithmic bytes of the reference stage(s) it implements / its mean
+        # HIP-event time in the warm-up)
+        "per_stage_roofline": per_stage_roofline(warm, n, num_cells, not args.reference_order),
         "scene_build_s": t_gen,
     }
-    if not args.no_cpu_baseline:
+    if iisph:
+        out["config"]["solver_iterations_last_step"] = s.last_iterations
+    if not args.no_cpu_baseline and not iisph:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
 
