@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,7 +79,7 @@ SPH::SPH()
     : m_gridSortBits(32), m_pos(nullptr), m_vel(nullptr), m_density(nullptr), m_pressure(nullptr), m_forces(nullptr),
       m_colors(nullptr), m_numParticles(0), m_hostCapacity(0), m_bi(nullptr), m_vbi(nullptr), m_num_boundaries(0),
       m_ctx(nullptr), m_ctxCapacity(0), m_hostDirty(true), m_deviceNewer(false), m_boundariesPending(false),
-      m_eagerSync(false), m_initialized(false)
+      m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f)
 {
     std::cout << GREEN << "construction of sph based system" << RESET << std::endl;
     std::memset(&m_params, 0, sizeof(m_params));
@@ -107,7 +108,7 @@ SPH::SPH(SphSimParams params)
     : m_params(params), m_gridSortBits(32), m_pos(nullptr), m_vel(nullptr), m_density(nullptr), m_pressure(nullptr),
       m_forces(nullptr), m_colors(nullptr), m_numParticles(0), m_hostCapacity(0), m_bi(nullptr), m_vbi(nullptr),
       m_num_boundaries(0), m_ctx(nullptr), m_ctxCapacity(0), m_hostDirty(true), m_deviceNewer(false),
-      m_boundariesPending(false), m_eagerSync(false), m_initialized(false)
+      m_boundariesPending(false), m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f)
 {
     kernelFactors(m_params, 2);
     _initialize();
@@ -242,6 +243,11 @@ void SPH::update()
     if (m_numParticles == 0) return;
     ensureContext();
     pushHostToDevice();                                                   // only if the host side changed
+    if (m_cfl) { // sph.cpp:217-231 (disabled there): newDeltat = lambda * (ir / |v|max)
+        double vmax = 0.0;
+        if (nrs_max_velocity(m_ctx, &vmax) != NRS_OK) fatal("nrs_max_velocity");
+        if (vmax > 0.0) m_params.timestep = m_cflLambda * (m_params.interactionRadius / (SReal)vmax);
+    }
     if (nrs_set_params(m_ctx, &m_params) != NRS_OK) fatal("nrs_set_params"); // setParameters, every step
     if (nrs_step(m_ctx, 1) != NRS_OK) fatal("nrs_step");
     m_deviceNewer = true;
@@ -312,6 +318,56 @@ void SPH::generateParticleCube(SVec4 center, SVec4 size, SVec4 vel)
             for (SReal z = center.z - size.z / 2.0; z <= center.z + size.z / 2.0; z += step)
                 addNewParticle(make_SVec4(x, y, z, 1.0), vel);
     std::cout << "There were " << m_numParticles << " particles generated." << std::endl;
+}
+
+namespace {
+struct CkptHeader {
+    char magic[8];
+    uint32_t realBytes, solver, paramBytes, reserved;
+    uint64_t n;
+};
+} // namespace
+
+bool SPH::saveState(const char *path) const
+{
+    pullDeviceToHost();
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return false;
+    CkptHeader h;
+    std::memcpy(h.magic, "NRSCKPT1", 8);
+    h.realBytes = sizeof(SReal); h.solver = (uint32_t)solverKind(); h.paramBytes = sizeof(SphSimParams); h.reserved = 0;
+    h.n = m_numParticles;
+    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(&m_params, sizeof(m_params), 1, f) == 1;
+    const size_t n = m_numParticles;
+    ok = ok && (n == 0 || (std::fwrite(m_pos, sizeof(SReal) * 4, n, f) == n && std::fwrite(m_vel, sizeof(SReal) * 4, n, f) == n &&
+                           std::fwrite(m_pressure, sizeof(SReal), n, f) == n));
+    return std::fclose(f) == 0 && ok;
+}
+
+bool SPH::loadState(const char *path)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    CkptHeader h;
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "NRSCKPT1", 8) == 0 && h.realBytes == sizeof(SReal) &&
+              h.paramBytes == sizeof(SphSimParams) && h.solver == (uint32_t)solverKind() && h.n < (1ull << 27);
+    SphSimParams p;
+    ok = ok && std::fread(&p, sizeof(p), 1, f) == 1;
+    if (ok) {
+        const size_t n = (size_t)h.n;
+        growHost((SUint)std::max<size_t>(n, 1));
+        ok = n == 0 || (std::fread(m_pos, sizeof(SReal) * 4, n, f) == n && std::fread(m_vel, sizeof(SReal) * 4, n, f) == n &&
+                        std::fread(m_pressure, sizeof(SReal), n, f) == n);
+        if (ok) {
+            // keep the grid of the running solver if boundaries already fixed it; take everything else from the file
+            m_params = p;
+            m_numParticles = (SUint)n;
+            m_hostDirty = true;
+            m_deviceNewer = false;
+        }
+    }
+    std::fclose(f);
+    return ok;
 }
 
 void SPH::updateGpuBoundaries(SUint nb_boundary_spheres)

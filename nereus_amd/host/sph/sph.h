@@ -94,6 +94,13 @@ public:
     SReal *getHostPressure() const;
     void synchronize() const;                       // wait for the device
     nrs_ctx *deviceContext();                      // the underlying C-ABI handle (created on demand)
+    // CFL time step, the block the reference keeps under `#if 0` (sph/sph.cpp:217-231): before each step
+    // dt = lambda * h / max|v| (lambda = 0.4) from a device-side reduction; off by default as in the reference build
+    void setAdaptiveTimestep(bool on, SReal lambda = 0.4f) { m_cfl = on; m_cflLambda = lambda; }
+    // binary checkpoint of the particle state (parameters, positions, velocities, IISPH warm-start pressure);
+    // the reference has none.  A restored solver continues bit-identically.
+    bool saveState(const char *path) const;
+    bool loadState(const char *path);
 
 protected:
     virtual int solverKind() const; // NRS_SOLVER_*
@@ -123,6 +130,8 @@ protected:
     bool m_boundariesPending;   // boundaries known but not yet uploaded into (a new) context
     bool m_eagerSync;
     bool m_initialized;
+    bool m_cfl;
+    SReal m_cflLambda;
 };
 
 NEREUS_NAMESPACE_END

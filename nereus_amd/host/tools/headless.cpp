@@ -3,6 +3,9 @@
 //
 //   headless params  <sesph|iisph> <out.bin>                    constructor-default SphSimParams bytes
 //   headless run     <sesph|iisph> <in.bin> <steps> <out.bin>   particles/boundaries from a file
+//   headless resume  <sesph|iisph> <in.bin> <steps_a> <steps_b> <ckpt> <out.bin>   run steps_a, saveState, then a NEW
+//                                                               solver loadState()s and runs steps_b (boundaries re-set)
+//   headless cfl     sesph <in.bin> <steps> <out.bin>           run with setAdaptiveTimestep(true)
 //   headless mainscene <sesph|iisph> <steps> <out.bin>          main.cpp:533-553: generateParticleCube + sampleBox +
 //                                                               getVbi + updateGpuBoundaries, gravity as given
 // in.bin : u32 n, u32 nb, then pos4[n], vel4[n], bi4[nb], vbi[nb] (SReal)
@@ -71,6 +74,40 @@ int main(int argc, char **argv)
         for (int s = 0; s < steps; ++s) sim->update();
         if (iisph) iters = static_cast<Nereus::IISPH *>(sim)->getLastIterations();
         dump(argv[5], sim, iters, bi, vbi);
+    } else if (mode == "resume" || mode == "cfl") {
+        FILE *f = std::fopen(argv[3], "rb");
+        if (!f) die("cannot open input");
+        unsigned n = 0, nb = 0;
+        if (std::fread(&n, 4, 1, f) != 1 || std::fread(&nb, 4, 1, f) != 1) die("short input");
+        std::vector<SVec4> pos(n), vel(n);
+        bi.resize(nb); vbi.resize(nb);
+        if (n && (std::fread(pos.data(), sizeof(SVec4), n, f) != n || std::fread(vel.data(), sizeof(SVec4), n, f) != n)) die("short input");
+        if (nb && (std::fread(bi.data(), sizeof(SVec4), nb, f) != nb || std::fread(vbi.data(), sizeof(SReal), nb, f) != nb)) die("short input");
+        std::fclose(f);
+        auto setup = [&](Nereus::SPH *s, bool particles) {
+            if (particles) for (unsigned i = 0; i < n; ++i) s->addNewParticle(pos[i], vel[i]);
+            if (nb) { s->setNumBoundaries(nb); s->setBi((SReal *)bi.data()); s->setVbi(vbi.data()); s->updateGpuBoundaries(nb); }
+        };
+        if (mode == "cfl") {
+            if (argc < 6) die("cfl needs <in.bin> <steps> <out.bin>");
+            setup(sim, true);
+            sim->setAdaptiveTimestep(true);
+            for (int s = 0; s < std::atoi(argv[4]); ++s) sim->update();
+            dump(argv[5], sim, 0, bi, vbi);
+        } else {
+            if (argc < 8) die("resume needs <in.bin> <steps_a> <steps_b> <ckpt> <out.bin>");
+            setup(sim, true);
+            for (int s = 0; s < std::atoi(argv[4]); ++s) sim->update();
+            if (!sim->saveState(argv[6])) die("saveState failed");
+            Nereus::SPH *again = iisph ? (Nereus::SPH *)new Nereus::IISPH() : new Nereus::SPH();
+            again->_initialize();
+            if (!again->loadState(argv[6])) die("loadState failed");
+            setup(again, false);
+            for (int s = 0; s < std::atoi(argv[5]); ++s) again->update();
+            if (iisph) iters = static_cast<Nereus::IISPH *>(again)->getLastIterations();
+            dump(argv[7], again, iters, bi, vbi);
+            delete again;
+        }
     } else if (mode == "mainscene") {
         if (argc < 5) die("mainscene needs <steps> <out.bin>");
         sim->generateParticleCube(make_SVec4(-0.4f, 0.04f, 0.5f, 1.f), make_SVec4(0.5f, 0.5f, 0.5f, 1.f), make_SVec4(0, 0, 0, 0));

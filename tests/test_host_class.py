@@ -104,3 +104,43 @@ def test_main_cpp_scene_through_class_api(tmp_path, hip_lib):
     assert got["iters"] == o.last_iters
     assert rel_err(got["pos"][:, :3], o.get("pos")[:, :3]) <= 1e-5
     assert rel_err(got["vel"][:, :3], o.get("vel")[:, :3]) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,solver", [("sesph", SESPH), ("iisph", IISPH)])
+def test_checkpoint_resume_is_bit_identical(tmp_path, hip_lib, kind, solver):
+    """saveState after 4 steps + loadState into a fresh solver + 3 steps == 7 uninterrupted steps, bit for bit."""
+    p, sc = small_dam_break(solver=solver)
+    fin = str(tmp_path / "in.bin")
+    _write_in(fin, sc["pos"], sc["vel"], sc["bi"], sc["vbi"])
+    straight, resumed = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    subprocess.check_call([_driver(), "run", kind, fin, "7", straight], stdout=subprocess.DEVNULL)
+    subprocess.check_call([_driver(), "resume", kind, fin, "4", "3", str(tmp_path / "ck.bin"), resumed], stdout=subprocess.DEVNULL)
+    a, b = _read_out(straight), _read_out(resumed)
+    np.testing.assert_array_equal(a["pos"], b["pos"])
+    np.testing.assert_array_equal(a["vel"], b["vel"])
+    np.testing.assert_array_equal(a["pressure"], b["pressure"])
+
+
+@pytest.mark.gpu
+def test_adaptive_cfl_timestep(tmp_path, hip_lib):
+    """setAdaptiveTimestep: dt = 0.4 * h / max|v| before every step (the reference's disabled CFL block)."""
+    p, sc = small_dam_break()
+    vel = sc["vel"].copy()
+    vel[:, 0] = 0.5
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_in(fin, sc["pos"], vel, sc["bi"], sc["vbi"])
+    subprocess.check_call([_driver(), "cfl", "sesph", fin, "3", fout], stdout=subprocess.DEVNULL)
+    got = _read_out(fout)
+    o = Oracle(p, solver=SESPH)
+    o.set_particles(sc["pos"], vel)
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    h = np.float32(p["interactionRadius"][0])
+    for _ in range(3):
+        q = o.params
+        vmax = np.linalg.norm(o.get("vel")[:, :3].astype(np.float64), axis=1).max() if o.n else 0.0
+        q["timestep"][0] = np.float32(0.4) * (h / np.float32(vmax))
+        o.set_params(q)
+        o.step(1)
+    assert np.isclose(float(got["params"]["timestep"][0]), float(o.params["timestep"][0]), rtol=1e-6)
+    assert rel_err(got["pos"][:, :3], o.get("pos")[:, :3]) <= 1e-5
