@@ -65,6 +65,24 @@ struct DevBuf {
 
 static inline uint32_t nblocks(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
 
+// Radix sort of (hash, index) pairs.  rocPRIM's onesweep sorts 8 key bits per pass by default, so the 25-27-bit
+// hashes of the dam-break grids take 4 passes; with 9 bits per pass they take 3.
+using SortCfg9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, 9,
+                                                                                rocprim::block_radix_rank_algorithm::match>>;
+using SortCfg10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, 10,
+                                                                                 rocprim::block_radix_rank_algorithm::match>>;
+static inline hipError_t sort_pairs(void *tmp, size_t &bytes, rocprim::double_buffer<uint32_t> &k, rocprim::double_buffer<uint32_t> &v,
+                                    size_t n, unsigned bits, hipStream_t stream)
+{
+    static const int mode = getenv("NEREUS_SORT_BITS") ? atoi(getenv("NEREUS_SORT_BITS")) : 0;
+    const bool wide = mode != 8; // NEREUS_SORT_BITS=8 forces rocPRIM's default 8-bit passes
+    if (wide && bits > 24 && bits <= 27) return rocprim::radix_sort_pairs<SortCfg9>(tmp, bytes, k, v, n, 0u, bits, stream);
+    if (wide && bits > 27 && bits <= 30) return rocprim::radix_sort_pairs<SortCfg10>(tmp, bytes, k, v, n, 0u, bits, stream);
+    return rocprim::radix_sort_pairs(tmp, bytes, k, v, n, 0u, bits, stream);
+}
+
 static uint32_t next_pow2(uint32_t v) // sph/sph.cpp:300-311
 {
     v--;
@@ -211,7 +229,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         rocprim::double_buffer<uint32_t> k(hashA.as<uint32_t>(), hashB.as<uint32_t>());
         rocprim::double_buffer<uint32_t> vv(indexA.as<uint32_t>(), indexB.as<uint32_t>());
         HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, k, vv, (size_t)cap, 0u, 32u, stream));
-        NRSCHK(sortTmp.alloc(tmp));
+        size_t tmp9 = 0;
+        HIPCHK(rocprim::radix_sort_pairs<SortCfg9>(nullptr, tmp9, k, vv, (size_t)cap, 0u, 27u, stream));
+        size_t tmp10 = 0;
+        HIPCHK(rocprim::radix_sort_pairs<SortCfg10>(nullptr, tmp10, k, vv, (size_t)cap, 0u, 30u, stream));
+        NRSCHK(sortTmp.alloc(std::max(tmp, std::max(tmp9, tmp10))));
         NRSCHK(alloc_cells());
         return NRS_OK;
     }
@@ -425,7 +447,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         rocprim::double_buffer<uint32_t> k(kIn, kAlt);
         rocprim::double_buffer<uint32_t> v(vIn, vAlt);
         size_t tmp = sortTmp.bytes;
-        HIPCHK(rocprim::radix_sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, 0u, sort_end_bit(), stream));
+        HIPCHK(sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, sort_end_bit(), stream));
         hashCur = k.current(); indexCur = v.current();
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_SORT) return NRS_OK;
