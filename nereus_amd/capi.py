@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libnereus_hip.so")
 SESPH, IISPH = 0, 1
 MONAGHAN, MULLER = 0, 1
 FLAG_REFERENCE_ORDER = 1
+FLAG_NO_FUSION = 4
+FLAG_NO_SHARED_LISTS = 8
 
 # NRS_STAGE_*
 STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
@@ -117,7 +119,7 @@ class Solver:
     """Thin object wrapper over an nrs_ctx (device-resident SESPH / IISPH solver)."""
 
     def __init__(self, params, capacity, solver=SESPH, double=False, kernel_set=MULLER, surface_tension=True,
-                 reference_order=False, device=-1, stream=None):
+                 reference_order=False, device=-1, stream=None, flags=0):
         self.lib = load_library()
         self.double = bool(double)
         self.real = np.float64 if double else np.float32
@@ -130,7 +132,7 @@ class Solver:
         cfg.precision = 64 if double else 32
         cfg.kernel_set = kernel_set
         cfg.surface_tension = int(bool(surface_tension))
-        cfg.flags = FLAG_REFERENCE_ORDER if reference_order else 0
+        cfg.flags = (FLAG_REFERENCE_ORDER if reference_order else 0) | int(flags)
         cfg.capacity = int(capacity)
         cfg.stream = stream
         h = C.c_void_p()

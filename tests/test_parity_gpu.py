@@ -158,6 +158,22 @@ def test_tiled_equals_reference_order_bitwise(hip_lib):
         np.testing.assert_array_equal(a, b)
 
 
+def test_kernel_path_flags_are_bitwise_equivalent(hip_lib):
+    """Fused vs separate force/integrate/hash launches, shared hit lists vs a second scan: same bits."""
+    p, sc = small_dam_break((20, 16, 14))
+    outs = []
+    for flags in (0, capi.FLAG_NO_FUSION, capi.FLAG_NO_SHARED_LISTS, capi.FLAG_NO_FUSION | capi.FLAG_NO_SHARED_LISTS):
+        s = capi.Solver(p, len(sc["pos"]), flags=flags)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step(7)
+        outs.append(s.download() + (s.get("hash"), s.get("index"), s.get("dens")))
+        s.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_edge_cases(hip_lib):
     p = Oracle.default_params(SESPH)
     # empty: stepping an empty solver is a no-op
