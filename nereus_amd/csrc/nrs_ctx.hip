@@ -145,6 +145,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     uint64_t nOwned = 0;
     uint32_t ghostCount = 0;
     bool cellsClean = false; // cellStart is all-EMPTY
+    bool packedHashValid = false;
     bool fusedThisStep = false;
     // profiling
     struct Ev { int stage; hipEvent_t a, b; };
@@ -628,7 +629,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
         if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
         const uint32_t N = (uint32_t)n;
-        const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_BLOCK - 1) / SLAB_BLOCK);
+        const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_TILE - 1) / SLAB_TILE);
         NRSCHK(slabCounts.alloc((size_t)ST_COUNT * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
         NRSCHK(slabTotals.alloc(ST_COUNT * 4));
         NRSCHK(ghostPos.alloc(sizeof(T4) * cap));
@@ -641,6 +642,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                                slabTotals.as<uint32_t>());
             SlabOut<R> out;
             out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
+            out.hash = hashA.as<uint32_t>(); out.index = indexA.as<uint32_t>(); // the hash pass of the next step, done here
             out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
             out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
             out.cap = (uint32_t)cap;
@@ -661,13 +663,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
         if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
         hashReady = false;
+        packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];
         if (counts) std::memcpy(counts, tot, sizeof(tot));
         return NRS_OK;
     }
-    uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_BLOCK - 1) / SLAB_BLOCK); }
+    uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_TILE - 1) / SLAB_TILE); }
 
     int slab_unpack(const void *recvL, const void *recvR, uint64_t mcap) override
     {
@@ -692,11 +695,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         A.start[0] = 0;
         for (int k = 0; k < 5; ++k) A.start[k + 1] = A.start[k] + len[k];
         if (A.start[5])
-            hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, A,
-                               posA.as<T4>(), velA.as<T4>(), (uint32_t)n);
+            hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, P, A,
+                               posA.as<T4>(), velA.as<T4>(), hashA.as<uint32_t>(), indexA.as<uint32_t>(), (uint32_t)n);
         HIPCHK(hipGetLastError());
         nOwned = n + hL[0] + hR[0];
         n = total;
+        // pack + unpack have written the radix keys/values of every local particle
+        hashNext = hashA.as<uint32_t>(); indexNext = indexA.as<uint32_t>();
+        hashReady = packedHashValid;
         return NRS_OK;
     }
 

@@ -22,6 +22,8 @@ namespace nrs {
 
 enum { ST_STAY = 0, ST_MIG_L = 1, ST_HALO_L = 2, ST_MIG_R = 3, ST_HALO_R = 4, ST_GHOST = 5, ST_COUNT = 6 };
 constexpr int SLAB_BLOCK = 256;
+constexpr int SLAB_ITERS = 8;                       // sub-tiles per workgroup: 2048 particles per workgroup keeps the block-
+constexpr int SLAB_TILE = SLAB_BLOCK * SLAB_ITERS;  // offset scan short (it was the most expensive slab kernel at 256)
 
 struct SlabCfg { int lo, hi, halo; };
 
@@ -44,7 +46,7 @@ template <typename R> NRS_DEV uint32_t slab_flags(const Params<R> &P, const Slab
     return f;
 }
 
-// pass 1: per-block population of every stream
+// pass 1: per-workgroup population of every stream
 template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
                                                           uint32_t n, uint32_t *__restrict__ blockCounts, uint32_t nBlocks)
@@ -52,11 +54,13 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg 
     __shared__ uint32_t cnt[ST_COUNT];
     if (threadIdx.x < ST_COUNT) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    const uint32_t f = i < n ? slab_flags<R>(P, c, pos[i]) : 0u;
-    for (int s = 0; s < ST_COUNT; ++s) {
-        const unsigned long long m = __ballot((f >> s) & 1u);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[s], (uint32_t)__popcll(m));
+    for (int it = 0; it < SLAB_ITERS; ++it) {
+        const uint32_t i = blockIdx.x * SLAB_TILE + it * SLAB_BLOCK + threadIdx.x;
+        const uint32_t f = i < n ? slab_flags<R>(P, c, pos[i]) : 0u;
+        for (int s = 0; s < ST_COUNT; ++s) {
+            const unsigned long long m = __ballot((f >> s) & 1u);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[s], (uint32_t)__popcll(m));
+        }
     }
     __syncthreads();
     if (threadIdx.x < ST_COUNT) blockCounts[threadIdx.x * nBlocks + blockIdx.x] = cnt[threadIdx.x];
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scan(uint32_t *__restrict__
 template <typename R> struct SlabOut {
     typedef typename Vec4T<R>::type T4;
     T4 *stayPos, *stayVel;   // compacted owned particles
+    uint32_t *hash, *index;  // radix-sort keys/values of the next step for the compacted particles (saves a hash pass)
     T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
     unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
     uint32_t cap;            // particles per message buffer
@@ -105,7 +110,7 @@ template <typename R> NRS_DEV typename Vec4T<R>::type *msg_vel(unsigned char *bu
     return (typename Vec4T<R>::type *)(buf + 16 + (size_t)cap * sizeof(typename Vec4T<R>::type));
 }
 
-// pass 3: stable scatter of every stream
+// pass 3: stable scatter of every stream (also hashes the particles that stay, for the next step's sort)
 template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
                                                             const typename Vec4T<R>::type *__restrict__ vel, uint32_t n,
@@ -114,43 +119,61 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
 {
     typedef typename Vec4T<R>::type T4;
     __shared__ uint32_t waveCnt[ST_COUNT][SLAB_BLOCK / 64];
-    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    __shared__ uint32_t run[ST_COUNT]; // particles of each stream already emitted by this workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T4 p, v;
-    uint32_t f = 0;
-    if (i < n) { p = pos[i]; v = vel[i]; f = slab_flags<R>(P, c, p); }
-    uint32_t rankInWave[ST_COUNT];
-    for (int s = 0; s < ST_COUNT; ++s) {
-        const unsigned long long m = __ballot((f >> s) & 1u);
-        rankInWave[s] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) waveCnt[s][wave] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    if (!f) return;
-    T4 tagged = p;
-    tagged.w = (R)2; // read-only copy
-    for (int s = 0; s < ST_COUNT; ++s) {
-        if (!((f >> s) & 1u)) continue;
-        uint32_t idx = blockOffsets[(size_t)s * nBlocks + blockIdx.x] + rankInWave[s];
-        for (uint32_t w = 0; w < wave; ++w) idx += waveCnt[s][w];
-        switch (s) {
-        case ST_STAY: out.stayPos[idx] = p; out.stayVel[idx] = v; break;
-        case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
-        case ST_MIG_L:
-            if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = p; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
-            break;
-        case ST_HALO_L:
-            idx += totals[ST_MIG_L];
-            if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = tagged; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
-            break;
-        case ST_MIG_R:
-            if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = p; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
-            break;
-        case ST_HALO_R:
-            idx += totals[ST_MIG_R];
-            if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = tagged; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
-            break;
+    if (threadIdx.x < ST_COUNT) run[threadIdx.x] = 0;
+    for (int it = 0; it < SLAB_ITERS; ++it) {
+        const uint32_t i = blockIdx.x * SLAB_TILE + it * SLAB_BLOCK + threadIdx.x;
+        T4 p, v;
+        uint32_t f = 0;
+        if (i < n) { p = pos[i]; v = vel[i]; f = slab_flags<R>(P, c, p); }
+        uint32_t rankInWave[ST_COUNT];
+        for (int s = 0; s < ST_COUNT; ++s) {
+            const unsigned long long m = __ballot((f >> s) & 1u);
+            rankInWave[s] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) waveCnt[s][wave] = (uint32_t)__popcll(m);
         }
+        __syncthreads();
+        if (f) {
+            T4 tagged = p;
+            tagged.w = (R)2; // read-only copy
+            for (int s = 0; s < ST_COUNT; ++s) {
+                if (!((f >> s) & 1u)) continue;
+                uint32_t idx = blockOffsets[(size_t)s * nBlocks + blockIdx.x] + run[s] + rankInWave[s];
+                for (uint32_t w = 0; w < wave; ++w) idx += waveCnt[s][w];
+                switch (s) {
+                case ST_STAY: {
+                    out.stayPos[idx] = p; out.stayVel[idx] = v;
+                    const I3 g = calcGridPos<R>(P, xyz<R>(p));
+                    out.hash[idx] = calcGridHash<R>(P, g.x, g.y, g.z);
+                    out.index[idx] = idx;
+                    break;
+                }
+                case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
+                case ST_MIG_L:
+                    if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = p; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
+                    break;
+                case ST_HALO_L:
+                    idx += totals[ST_MIG_L];
+                    if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = tagged; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
+                    break;
+                case ST_MIG_R:
+                    if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = p; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
+                    break;
+                case ST_HALO_R:
+                    idx += totals[ST_MIG_R];
+                    if (out.sendR && idx < out.cap) { msg_pos<R>(out.sendR)[idx] = tagged; msg_vel<R>(out.sendR, out.cap)[idx] = v; }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < ST_COUNT) {
+            uint32_t t = 0;
+            for (int w = 0; w < SLAB_BLOCK / 64; ++w) t += waveCnt[threadIdx.x][w];
+            run[threadIdx.x] += t;
+        }
+        __syncthreads();
     }
 }
 
@@ -174,16 +197,21 @@ template <typename R> struct AppendPieces {
     uint32_t start[6]; // exclusive prefix of the piece lengths; start[5] = total
 };
 template <typename R>
-__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
-                                                           typename Vec4T<R>::type *__restrict__ dstVel, uint32_t dstBase)
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
+                                                           typename Vec4T<R>::type *__restrict__ dstVel, uint32_t *__restrict__ hash,
+                                                           uint32_t *__restrict__ index, uint32_t dstBase)
 {
     const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (i >= A.start[5]) return;
     int k = 0;
     while (k < 4 && i >= A.start[k + 1]) ++k;
     const uint32_t j = i - A.start[k];
-    dstPos[dstBase + i] = A.srcPos[k][j];
+    const typename Vec4T<R>::type p = A.srcPos[k][j];
+    dstPos[dstBase + i] = p;
     dstVel[dstBase + i] = A.srcVel[k][j];
+    const I3 g = calcGridPos<R>(P, xyz<R>(p));
+    hash[dstBase + i] = calcGridHash<R>(P, g.x, g.y, g.z);
+    index[dstBase + i] = dstBase + i;
 }
 
 } // namespace nrs
