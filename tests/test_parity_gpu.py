@@ -158,6 +158,40 @@ def test_tiled_equals_reference_order_bitwise(hip_lib):
         np.testing.assert_array_equal(a, b)
 
 
+def test_hash_bit_exact_on_adversarial_positions(hip_lib):
+    """calcGridPos/calcGridHash (sph_kernel_impl.cuh:105-125): positions exactly on, and one ulp either side of, cell
+    faces (where a reciprocal-multiply or a contracted FMA would flip floor()), far outside the grid (wrap, negative
+    cells), for several grids and origins — hash must match the oracle bit for bit."""
+    rng = np.random.default_rng(2024)
+    base = Oracle.default_params(SESPH)
+    for grid, origin, h in (((64, 64, 64), (-1.1, -1.1, -1.1), 0.0457), ((128, 32, 256), (0.013, -7.5, 2.25), 0.0537),
+                            ((1024, 512, 256), (-0.1, -0.1, -0.1), 0.0457)):
+        p = base.copy()
+        p["gridSize"][0] = grid
+        p["numCells"][0] = int(np.prod(grid))
+        p["worldOrigin"][0] = origin
+        p["interactionRadius"][0] = h
+        p["cellSize"][0] = (h, h, h)
+        p = Oracle.recompute_constants(p)
+        o32 = np.array(p["worldOrigin"][0], np.float32)
+        c32 = np.float32(p["cellSize"][0][0])
+        k = rng.integers(-3, max(grid) + 3, size=(20000, 3)).astype(np.float32)
+        face = (o32 + k * c32).astype(np.float32)            # nominally on a cell face
+        pts = [face, np.nextafter(face, np.float32(np.inf)), np.nextafter(face, np.float32(-np.inf)),
+               rng.uniform(-50, 50, (20000, 3)).astype(np.float32),
+               (o32 + rng.uniform(0, 1, (20000, 3)).astype(np.float32) * (np.array(grid, np.float32) * c32)).astype(np.float32)]
+        pos = np.ones((sum(len(a) for a in pts), 4), np.float32)
+        pos[:, :3] = np.concatenate(pts)
+        o, s = make_pair(p, pos, np.zeros_like(pos))
+        o.step(1, stop=STOP_HASH); s.step_partial(capi.STAGE_HASH)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+        s.set_particles(pos, None)
+        o.step(1, stop=STOP_REORDER); s.step_partial(capi.STAGE_REORDER)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+        np.testing.assert_array_equal(s.get("index"), o.get("index"))
+        check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
+
+
 def test_kernel_path_flags_are_bitwise_equivalent(hip_lib):
     """Fused vs separate force/integrate/hash launches, shared hit lists vs a second scan: same bits."""
     p, sc = small_dam_break((20, 16, 14))
