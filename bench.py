@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--config", default="NS", help="scene lattice: NS (216^3), C2 (100^3), C4, C1 ... or nx,ny,nz")
     ap.add_argument("--solver", default="sesph", choices=["sesph", "iisph"],
                     help="sesph = the BASELINE metric (default); iisph = config 3 style run of the IISPH chain (N=1 only)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = every rank gets a block of --config size (default, the driver contract); strong = the "
+                         "--config lattice is split across the ranks in x (e.g. --config C4 --gpus 8: 16M particles, 2M per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
     args = ap.parse_args()
@@ -173,7 +176,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
 
+        if args.scaling == "strong":
+            if lattice[0] % world:
+                raise SystemExit("--scaling strong needs the x extent of the lattice (%d) divisible by --gpus" % lattice[0])
+            lattice = (lattice[0] // world,) + tuple(lattice[1:])
         result = slab.bench_main(args, lattice, rank, world, local_rank)
+        result["scaling"] = args.scaling
         if rank == 0:
             print(json.dumps(result))
         return
