@@ -229,6 +229,10 @@ int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right,
 /* owned particles (the first nrs_num_owned() entries of NRS_ARR_POS/VEL right after nrs_slab_pack/unpack) */
 uint64_t nrs_num_owned(nrs_ctx *ctx);
 uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision);
+/* Owned particles (pos.w == 1) per global cell-x column first_cell .. first_cell+ncells-1, to host memory: the input
+ * of a count-balanced re-cut.  New cuts are applied by calling nrs_slab_configure again; particles that now belong
+ * to a neighbour leave with the next nrs_slab_pack (a cut may therefore move by less than a slab width at a time). */
+int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);

@@ -45,7 +45,7 @@ EXPORTS = [
     "nrs_step", "nrs_step_partial", "nrs_synchronize", "nrs_download", "nrs_get_array", "nrs_device_ptr",
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
-    "nrs_slab_message_bytes",
+    "nrs_slab_message_bytes", "nrs_slab_histogram",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library(path=None):
     lib.nrs_num_owned.restype = u64
     lib.nrs_slab_message_bytes.argtypes = [u64, i32]
     lib.nrs_slab_message_bytes.restype = u64
+    lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = lib
     return lib
 
@@ -262,6 +263,11 @@ class Solver:
 
     def slab_unpack(self, recv_left_ptr, recv_right_ptr, capacity):
         self._chk(self.lib.nrs_slab_unpack(self.h, recv_left_ptr, recv_right_ptr, int(capacity)))
+
+    def slab_histogram(self, first_cell, ncells):
+        out = (C.c_uint32 * int(ncells))()
+        self._chk(self.lib.nrs_slab_histogram(self.h, int(first_cell), int(ncells), out))
+        return np.frombuffer(out, dtype=np.uint32).copy()
 
     @property
     def n_owned(self):

@@ -110,6 +110,7 @@ struct CtxBase {
     virtual int slab_pack(void *sendL, void *sendR, uint64_t cap, uint32_t *counts) = 0;
     virtual int slab_unpack(const void *recvL, const void *recvR, uint64_t cap) = 0;
     virtual uint64_t num_owned() = 0;
+    virtual int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int device = 0;
@@ -622,6 +623,20 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
     uint64_t num_owned() override { return slabOn ? nOwned : n; }
+    int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) override
+    {
+        if (!nbins || !out) return fail(NRS_E_INVALID, "bad histogram request");
+        DevBuf bins;
+        NRSCHK(bins.alloc((size_t)nbins * 4));
+        HIPCHK(hipMemsetAsync(bins.p, 0, (size_t)nbins * 4, stream));
+        if (n)
+            hipLaunchKernelGGL((k_slab_histogram<R>), dim3((uint32_t)((n + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, stream, P,
+                               posA.as<T4>(), (uint32_t)n, lo0, nbins, bins.as<uint32_t>());
+        HIPCHK(hipMemcpyAsync(out, bins.p, (size_t)nbins * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        bins.release();
+        return NRS_OK;
+    }
 
     int slab_pack(void *sendL, void *sendR, uint64_t cap, uint32_t *counts) override
     {
@@ -974,6 +989,11 @@ int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right,
     return ctx->impl->slab_unpack(recv_left, recv_right, capacity);
 }
 uint64_t nrs_num_owned(nrs_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->num_owned() : 0; }
+int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->slab_histogram(first_cell, ncells, counts);
+}
 uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision) { return 16 + capacity * 2 * (precision == 64 ? 32 : 16); }
 
 int nrs_max_density(nrs_ctx *ctx, double *out)

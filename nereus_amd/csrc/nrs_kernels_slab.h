@@ -189,6 +189,19 @@ __global__ void k_slab_headers(const uint32_t *__restrict__ totals, unsigned cha
     }
 }
 
+// owned particles per grid cell-x column, bins [lo0, lo0 + nbins): input of the count-balanced re-cut
+template <typename R>
+__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_histogram(Params<R> P, const typename Vec4T<R>::type *__restrict__ pos, uint32_t n,
+                                                              int lo0, uint32_t nbins, uint32_t *__restrict__ bins)
+{
+    const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const typename Vec4T<R>::type q = pos[i];
+    if (!(q.w == (R)1)) return;
+    const long long cx = (long long)floor((q.x - P.worldOrigin[0]) / P.cellSize[0]) - lo0;
+    if (cx >= 0 && cx < (long long)nbins) atomicAdd(&bins[cx], 1u);
+}
+
 // append up to five (source, count) pieces behind the compacted owned particles
 template <typename R> struct AppendPieces {
     typedef typename Vec4T<R>::type T4;

@@ -46,6 +46,36 @@ def plane_cuts(nx_per_rank, world, h, origin_x, real=np.float32):
     return cuts
 
 
+def new_cuts(hist, old, halo, move_budget):
+    """Pure function behind SlabDriver.rebalance: `hist` = owned particles per cell-x column (whole grid), `old` =
+    current cuts (world+1 cell indices, the two outer ones open-ended).  Returns the new cuts."""
+    world = len(old) - 1
+    cum = np.concatenate([[0], np.cumsum(hist)])          # cum[c] = particles in columns < c
+    total = int(cum[-1])
+    new = list(old)
+    for k in range(1, world):
+        target = total * k // world
+        want = int(np.searchsorted(cum, target, side="left"))      # smallest c with cum[c] >= target
+        c = old[k]
+        lo_lim = old[k - 1] + 2 * halo if k > 1 else 2 * halo
+        hi_lim = old[k + 1] - 2 * halo if k < world - 1 else len(hist) - 2 * halo
+        want = max(min(want, hi_lim), lo_lim)
+        # walk towards `want` one column at a time while the particles changing owner fit the budget
+        step = 1 if want > c else -1
+        moved = 0
+        while c != want:
+            col = c if step > 0 else c - 1
+            n_col = int(hist[col]) if 0 <= col < len(hist) else 0
+            if moved + n_col > move_budget:
+                break
+            moved += n_col
+            c += step
+        new[k] = c
+    for k in range(1, world):  # keep every slab at least two halos wide
+        new[k] = max(new[k], (new[k - 1] if k > 1 else 0) + 2 * halo)
+    return new
+
+
 class HipSlabEngine:
     """Product engine: particles live in an nrs_ctx on this rank's GPU; buffers are torch CUDA tensors."""
 
@@ -82,6 +112,14 @@ class HipSlabEngine:
 
     def step(self, k=1):
         self.solver.step(k)
+
+    def histogram(self, first_cell, ncells):
+        """owned particles per global cell-x column (numpy int64)"""
+        return self.solver.slab_histogram(first_cell, ncells).astype(np.int64)
+
+    def set_cuts(self, cell_lo, cell_hi):
+        self.cell_lo, self.cell_hi = cell_lo, cell_hi
+        self.solver.slab_configure(cell_lo, cell_hi, self.halo)
 
     def synchronize(self):
         self.solver.synchronize()
@@ -153,6 +191,32 @@ class SlabDriver:
         for _ in range(k):
             self.exchange()
             self.engine.step(1)
+
+    def rebalance(self, grid_x, move_budget):
+        """Count-balanced re-cut (a dam-break starts with all fluid in one third of the tank and then
+        flows along x, so fixed cuts drift out of balance).  Call BEFORE exchange(): the new cuts must be in force when
+        the next partition decides who owns what, so that the step after it evaluates every particle on exactly one
+        rank.  Per-column counts of owned particles are summed over the ranks (one small all-reduce,
+        every K steps, outside the per-step data path); each interior cut moves towards the column where the
+        cumulative count reaches its share, but (a) by at most what `move_budget` particles allow, so the leavers fit
+        the fixed message buffers of the next exchange, (b) never past its neighbours' old cuts minus two halos, so
+        ownership only ever changes between adjacent ranks and no slab gets narrower than two halos.
+        Returns the new (lo, hi) of this rank."""
+        torch, dist, eng = self.torch, self.dist, self.engine
+        hist = torch.from_numpy(eng.histogram(0, grid_x))  # owned particles may have drifted past the cuts: whole grid
+        cuts = torch.zeros(self.world + 1, dtype=torch.int64)
+        cuts[self.rank] = eng.cell_lo
+        if self.rank == self.world - 1:
+            cuts[self.world] = eng.cell_hi
+        dev = getattr(eng, "device", None) if dist.get_backend(self.group) == "nccl" else None
+        if dev is not None:
+            hist, cuts = hist.to(dev), cuts.to(dev)
+        dist.all_reduce(hist, group=self.group)
+        dist.all_reduce(cuts, group=self.group)
+        hist, old = hist.cpu().numpy(), [int(v) for v in cuts.cpu().numpy()]
+        new = new_cuts(hist, old, eng.halo, move_budget)
+        eng.set_cuts(new[self.rank], new[self.rank + 1])
+        return new[self.rank], new[self.rank + 1]
 
     def finish(self):
         """Drop halo copies and hand over leavers one last time so that owned_state() is the true partition."""

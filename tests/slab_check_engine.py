@@ -85,6 +85,24 @@ class OracleSlabEngine:
             o.step(1)
             self.pos, self.vel = o.get("pos"), o.get("vel")
 
+    def histogram(self, first_cell, ncells):
+        ox, cs = float(self.p["worldOrigin"][0][0]), float(self.p["cellSize"][0][0])
+        live = self.pos[:, 3] == 1.0
+        cx = cell_of(self.pos[live, 0], ox, cs) - first_cell
+        cx = cx[(cx >= 0) & (cx < ncells)]
+        return np.bincount(cx, minlength=ncells).astype(np.int64)
+
+    def set_cuts(self, cell_lo, cell_hi):
+        self.lo, self.hi = cell_lo, cell_hi
+
+    @property
+    def cell_lo(self):
+        return self.lo
+
+    @property
+    def cell_hi(self):
+        return self.hi
+
     def synchronize(self):
         pass
 

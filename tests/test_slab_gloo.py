@@ -27,11 +27,11 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, use_hip, outdir):
+def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
-    from nereus_amd import slab
+    from nereus_amd import scene, slab
     from nereus_amd.params import default_params
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,6 +46,21 @@ def _worker(rank, world, port, steps, use_hip, outdir):
     iz = np.rint(pos[:, 2] / d - 1).astype(np.int64)
     vel[:, 3] = ((ix * ny + iy) * nz + iz).astype(np.float32)
     vel[:, 0] = np.where((iy + iz) % 2 == 0, 2.5, -2.5).astype(np.float32)  # make particles cross the cuts
+    if skew:  # deliberately unbalanced cuts (every interior cut moved by `skew` cells) to exercise the re-cut
+        cuts = [cuts[0]] + [c + skew for c in cuts[1:-1]] + [cuts[-1]]
+        ox, cs = float(p["worldOrigin"][0][0]), float(p["cellSize"][0][0])
+        full = scene.fluid_block(nx * world, ny, nz, float(p["interactionRadius"][0]))
+        cx = slab.cell_of(full[:, 0], ox, cs)
+        mine = (cx >= cuts[rank]) & (cx < cuts[rank + 1])
+        pos = full[mine]
+        vel = np.zeros_like(pos)
+        ix = np.rint(pos[:, 0] / d - 1).astype(np.int64)
+        iy = np.rint(pos[:, 1] / d - 1).astype(np.int64)
+        iz = np.rint(pos[:, 2] / d - 1).astype(np.int64)
+        vel[:, 3] = ((ix * ny + iy) * nz + iz).astype(np.float32)
+        vel[:, 0] = np.where((iy + iz) % 2 == 0, 2.5, -2.5).astype(np.float32)
+        full_scene = scene.dam_break((nx * world, ny, nz), h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+        bi, vbi = full_scene["bi"], full_scene["vbi"]  # every rank sees the whole (small) tank: cuts will move
     msg_cap = 4096
     if use_hip:
         eng = slab.HipSlabEngine(p, 8192, msg_cap, cuts[rank], cuts[rank + 1], 0)
@@ -56,25 +71,30 @@ def _worker(rank, world, port, steps, use_hip, outdir):
     eng.load(pos, vel, bi, vbi)
     drv = slab.SlabDriver(eng, rank, world, stage_through_host=use_hip)
     moved = 0
-    for _ in range(steps):
-        drv.step(1)
+    owned_hist = [len(pos)]
+    for it in range(steps):
+        if rebalance_every and it % rebalance_every == 0:
+            drv.rebalance(int(p["gridSize"][0][0]), move_budget=msg_cap // 2)
+        drv.exchange()
         moved += drv.last_counts[1] + drv.last_counts[3]
+        owned_hist.append(eng.n_owned)
+        eng.step(1)
     drv.finish()
     moved += drv.last_counts[1] + drv.last_counts[3]
     op, ov = eng.owned_state()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), pos=op, vel=ov, moved=moved, cuts=np.array(cuts[1:-1]),
-             params=p.view(np.uint8))
+             params=p.view(np.uint8), owned=np.array(owned_hist))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, steps, use_hip, tmp_path):
+def _run(world, steps, use_hip, tmp_path, skew=0, rebalance_every=0):
     from nereus_amd import scene
     from nereus_amd.params import default_params, params_dtype
     from tests.common import rel_err
     from tests.oracle_lib import SESPH, Oracle
 
-    mp.spawn(_worker, args=(world, _free_port(), steps, use_hip, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, use_hip, str(tmp_path), skew, rebalance_every), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     pos = np.concatenate([q["pos"] for q in parts])
     vel = np.concatenate([q["vel"] for q in parts])
@@ -101,6 +121,7 @@ def _run(world, steps, use_hip, tmp_path):
     order_got = np.argsort(ids)
     assert rel_err(pos[order_got][:, :3], rp[order_ref][:, :3]) <= 1e-5
     assert rel_err(vel[order_got][:, :3], rv[order_ref][:, :3]) <= 1e-5
+    _run.owned = [q["owned"] for q in parts]
     return sum(int(q["moved"]) for q in parts)
 
 
@@ -135,3 +156,34 @@ def test_message_capacity_rule_covers_the_halo():
         if rank > 0:
             assert hl > 0
         assert abs(len(pos) - np.prod(lattice)) <= 2 * lattice[1] * lattice[2]  # count-balanced to within two planes
+
+
+def test_new_cuts_rule():
+    from nereus_amd.slab import NO_CUT_HI, NO_CUT_LO, new_cuts
+
+    hist = np.zeros(64, np.int64)
+    hist[10:30] = 100                                     # 2000 particles in columns 10..29
+    old = [NO_CUT_LO, 14, NO_CUT_HI]
+    assert new_cuts(hist, old, 2, 10 ** 9) == [NO_CUT_LO, 20, NO_CUT_HI]          # unconstrained: the median column
+    assert new_cuts(hist, old, 2, 250) == [NO_CUT_LO, 16, NO_CUT_HI]              # budget: two columns of 100 fit, three do not
+    old3 = [NO_CUT_LO, 12, 16, NO_CUT_HI]
+    got = new_cuts(hist, old3, 2, 10 ** 9)
+    assert got[1] == 12 and got[2] == 24                  # cut 1 may not pass old cut 2 minus two halos; cut 2 reaches the 2/3 column
+    assert all(b - a >= 4 for a, b in zip(got[1:-2], got[2:-1]))
+
+
+def test_slab_rebalance_gloo_cpu(tmp_path):
+    """Start with cuts 3 cells off balance; re-cut every 2 steps under the message budget: the owned counts converge and
+    the result still equals the single-domain oracle."""
+    moved = _run(2, 10, False, tmp_path, skew=-3, rebalance_every=2)
+    owned = np.stack(_run.owned)          # (rank, step)
+    imbalance0 = abs(int(owned[0, 0]) - int(owned[1, 0]))
+    imbalance1 = abs(int(owned[0, -1]) - int(owned[1, -1]))
+    assert imbalance0 > 0 and imbalance1 < imbalance0 and moved > 0
+
+
+@pytest.mark.gpu
+def test_slab_rebalance_hip_engine(tmp_path, hip_lib):
+    moved = _run(2, 12, True, tmp_path, skew=-3, rebalance_every=2)
+    owned = np.stack(_run.owned)
+    assert abs(int(owned[0, -1]) - int(owned[1, -1])) < abs(int(owned[0, 0]) - int(owned[1, 0])) and moved > 0
