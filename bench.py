@@ -148,6 +148,7 @@ def main():
                          "--config lattice is split across the ranks in x (e.g. --config C4 --gpus 8: 16M particles, 2M per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
+    ap.add_argument("--full-sort", action="store_true", help="sort all pairs from scratch every step (NRS_FLAG_FULL_SORT)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,7 +198,7 @@ def main():
     n = len(sc["pos"])
     stream = torch.cuda.current_stream().cuda_stream
     s = capi.Solver(p, n, solver=capi.IISPH if iisph else capi.SESPH, device=local_rank, stream=stream,
-                    reference_order=args.reference_order)
+                    reference_order=args.reference_order, flags=capi.FLAG_FULL_SORT if args.full_sort else 0)
     s.set_particles(sc["pos"], sc["vel"])
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     P = s.params

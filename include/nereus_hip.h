@@ -71,6 +71,9 @@ enum {
                                            on the production kernels fuses them into the force kernel) */
     NRS_FLAG_NO_SHARED_LISTS = 1u << 3, /* the force kernel re-scans the neighbourhood instead of consuming the hit lists
                                            the density kernel of the same step found (saves HIT_CAP*4 B/particle of HBM) */
+    NRS_FLAG_FULL_SORT = 1u << 4,       /* sort all (hash, index) pairs from scratch every step, as the reference does
+                                           (sph_cuda.cu:310-313); default: only the particles that changed cell are
+                                           sorted and merged into the still-sorted rest (same result, element for element) */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };
@@ -233,6 +236,12 @@ uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision);
  * of a count-balanced re-cut.  New cuts are applied by calling nrs_slab_configure again; particles that now belong
  * to a neighbour leave with the next nrs_slab_pack (a cut may therefore move by less than a slab width at a time). */
 int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts);
+
+/* Coherent re-sort statistics since nrs_create: steps whose (hash, index) pairs were produced by sorting only the
+ * particles that changed cell and merging them into the rest, and how many of those fell back to the full radix sort
+ * because more than 1/8 of the particles had moved.  (Steps after an upload, partial steps, IISPH and slab runs always
+ * use the full sort and are not counted.) */
+int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);

@@ -19,6 +19,7 @@ MONAGHAN, MULLER = 0, 1
 FLAG_REFERENCE_ORDER = 1
 FLAG_NO_FUSION = 4
 FLAG_NO_SHARED_LISTS = 8
+FLAG_FULL_SORT = 16
 
 # NRS_STAGE_*
 STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
@@ -45,7 +46,7 @@ EXPORTS = [
     "nrs_step", "nrs_step_partial", "nrs_synchronize", "nrs_download", "nrs_get_array", "nrs_device_ptr",
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
-    "nrs_slab_message_bytes", "nrs_slab_histogram",
+    "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats",
 ]
 
 
@@ -108,6 +109,7 @@ def load_library(path=None):
     lib.nrs_slab_message_bytes.argtypes = [u64, i32]
     lib.nrs_slab_message_bytes.restype = u64
     lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.nrs_resort_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     _lib = lib
     return lib
 
@@ -268,6 +270,12 @@ class Solver:
         out = (C.c_uint32 * int(ncells))()
         self._chk(self.lib.nrs_slab_histogram(self.h, int(first_cell), int(ncells), out))
         return np.frombuffer(out, dtype=np.uint32).copy()
+
+    def resort_stats(self):
+        """(steps that used the coherent re-sort path, how many of them fell back to the full radix sort)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.nrs_resort_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     @property
     def n_owned(self):

@@ -19,6 +19,7 @@
 #include "nrs_kernels_tiled.h"
 #include "nrs_kernels_iisph.h"
 #include "nrs_kernels_slab.h"
+#include "nrs_kernels_resort.h"
 #include <climits>
 
 namespace nrs {
@@ -83,6 +84,20 @@ static inline hipError_t sort_pairs(void *tmp, size_t &bytes, rocprim::double_bu
     return rocprim::radix_sort_pairs(tmp, bytes, k, v, n, 0u, bits, stream);
 }
 
+// Radix sort of the movers of the coherent re-sort (nrs_kernels_resort.h): u64 keys "hash << 32 | slot", only the hash
+// bits are sorted (the slots are already ascending and the sort is stable).  A few hundred thousand keys: onesweep
+// from 8192 keys on (rocPRIM's default switches to its merge sort below 1 M keys: measured 104 vs 66 us at 300 k).
+template <unsigned BITS>
+using MoverSortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, BITS,
+                                                                                    rocprim::block_radix_rank_algorithm::match>, 8192>;
+static inline hipError_t sort_movers(void *tmp, size_t &bytes, rocprim::double_buffer<uint64_t> &k, size_t m, unsigned bits, hipStream_t stream)
+{
+    if (bits > 24 && bits <= 27) return rocprim::radix_sort_keys<MoverSortCfg<9>>(tmp, bytes, k, m, 32u, 32u + bits, stream);
+    if (bits > 27 && bits <= 30) return rocprim::radix_sort_keys<MoverSortCfg<10>>(tmp, bytes, k, m, 32u, 32u + bits, stream);
+    return rocprim::radix_sort_keys<MoverSortCfg<8>>(tmp, bytes, k, m, 32u, 32u + bits, stream);
+}
+
 static uint32_t next_pow2(uint32_t v) // sph/sph.cpp:300-311
 {
     v--;
@@ -111,6 +126,7 @@ struct CtxBase {
     virtual int slab_unpack(const void *recvL, const void *recvR, uint64_t cap) = 0;
     virtual uint64_t num_owned() = 0;
     virtual int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) = 0;
+    virtual void resort_stats(uint64_t *steps, uint64_t *fallbacks) = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int device = 0;
@@ -139,6 +155,12 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij;
     DevBuf redPartial, redOut;
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
+    // coherent re-sort (nrs_kernels_resort.h)
+    DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars;
+    uint32_t *rsHostTotal = nullptr, *rsHostTotalDev = nullptr; // mover count, written by k_resort_scan_tiles (pinned, mapped)
+    hipEvent_t rsEvent = nullptr;
+    bool rsPending = false; // movers/stayers of the keys in hashNext have been split; the count is on its way
+    uint64_t rsSteps = 0, rsFallbacks = 0;
     // slab decomposition
     bool slabOn = false;
     SlabCfg slab = {INT_MIN / 2, INT_MAX / 2, 2};
@@ -149,7 +171,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool packedHashValid = false;
     bool fusedThisStep = false;
     // profiling
-    struct Ev { int stage; hipEvent_t a, b; };
+    struct Ev { int stage; hipEvent_t a, b; bool cont; };
     std::vector<Ev> evPool;
     size_t evUsed = 0;
     float stageMs[NRS_STAGE_COUNT] = {0};
@@ -172,8 +194,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals};
+                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars};
         for (DevBuf *b : all) b->release();
+        if (rsEvent) (void)hipEventDestroy(rsEvent);
+        if (rsHostTotal) (void)hipHostFree(rsHostTotal);
         if (ownStream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -235,7 +260,31 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         HIPCHK(rocprim::radix_sort_pairs<SortCfg9>(nullptr, tmp9, k, vv, (size_t)cap, 0u, 27u, stream));
         size_t tmp10 = 0;
         HIPCHK(rocprim::radix_sort_pairs<SortCfg10>(nullptr, tmp10, k, vv, (size_t)cap, 0u, 30u, stream));
-        NRSCHK(sortTmp.alloc(std::max(tmp, std::max(tmp9, tmp10))));
+        size_t tmpAll = std::max(tmp, std::max(tmp9, tmp10));
+        // coherent re-sort: SESPH steps on the production kernels re-use the previous step's order
+        if (!iisph() && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_FUSION | NRS_FLAG_FULL_SORT)) && cap >= RESORT_MIN_PARTICLES) {
+            const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+            const size_t mcap = cap / RESORT_MAX_MOVER_DIV + 1;
+            NRSCHK(rsMovers.alloc(8 * cap)); NRSCHK(rsMoversAlt.alloc(8 * mcap)); NRSCHK(rsStayers.alloc(8 * cap)); NRSCHK(rsMerged.alloc(8 * cap));
+            NRSCHK(rsTileMovers.alloc(4 * nTiles)); NRSCHK(rsTileOffset.alloc(4 * nTiles));
+            NRSCHK(rsGroupTotal.alloc(4 * nGroups)); NRSCHK(rsGroupPrefix.alloc(4 * nGroups)); NRSCHK(rsScalars.alloc(8));
+            HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, 4 * nTiles, stream));
+            HIPCHK(hipMemsetAsync(rsScalars.p, 0, 8, stream));
+            HIPCHK(hipHostMalloc((void **)&rsHostTotal, 64, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer((void **)&rsHostTotalDev, rsHostTotal, 0));
+            HIPCHK(hipEventCreateWithFlags(&rsEvent, hipEventDisableTiming));
+            rocprim::double_buffer<uint64_t> mk(rsMovers.as<uint64_t>(), rsMoversAlt.as<uint64_t>());
+            for (unsigned bits : {24u, 27u, 30u}) {
+                size_t t = 0;
+                HIPCHK(sort_movers(nullptr, t, mk, mcap, bits, stream));
+                tmpAll = std::max(tmpAll, t);
+            }
+            size_t t = 0;
+            HIPCHK(rocprim::merge(nullptr, t, rsStayers.as<uint64_t>(), rsMovers.as<uint64_t>(), rsMerged.as<uint64_t>(), (size_t)cap, mcap,
+                                  rocprim::less<uint64_t>(), stream));
+            tmpAll = std::max(tmpAll, t);
+        }
+        NRSCHK(sortTmp.alloc(tmpAll));
         NRSCHK(alloc_cells());
         return NRS_OK;
     }
@@ -361,7 +410,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     }
 
     // ---- profiling helpers ------------------------------------------------------------------------
-    int ev_begin(int stage)
+    // cont: second part of a stage whose first part ran earlier (time is added, the launch count is not)
+    int ev_begin(int stage, bool cont = false)
     {
         evOpen = (profMask >> stage) & 1u;
         if (!evOpen) return NRS_OK;
@@ -372,6 +422,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             evPool.push_back(e);
         }
         evPool[evUsed].stage = stage;
+        evPool[evUsed].cont = cont;
         HIPCHK(hipEventRecord(evPool[evUsed].a, stream));
         return NRS_OK;
     }
@@ -391,7 +442,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, evPool[i].a, evPool[i].b));
             stageMs[evPool[i].stage] += ms;
-            stageLaunches[evPool[i].stage] += 1;
+            stageLaunches[evPool[i].stage] += evPool[i].cont ? 0 : 1;
         }
         evUsed = 0;
         return NRS_OK;
@@ -441,25 +492,59 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             hipLaunchKernelGGL((k_hash<R>), g, b, 0, stream, P, posA.as<T4>(), kIn, vIn, N);
             NRSCHK(ev_end());
         }
+        const bool resort = hashReady && rsPending && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT;
         hashReady = false;
+        rsPending = false;
         hashCur = kIn; indexCur = vIn;
         if (stop == NRS_STAGE_HASH) return NRS_OK;
 
-        NRSCHK(ev_begin(NRS_STAGE_SORT));
-        rocprim::double_buffer<uint32_t> k(kIn, kAlt);
-        rocprim::double_buffer<uint32_t> v(vIn, vAlt);
-        size_t tmp = sortTmp.bytes;
-        HIPCHK(sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, sort_end_bit(), stream));
-        hashCur = k.current(); indexCur = v.current();
+        const uint64_t *merged = nullptr;
+        NRSCHK(ev_begin(NRS_STAGE_SORT, resort));
+        if (resort) {
+            // the split of these keys into movers / stayers was queued behind the force kernel; its mover count sizes
+            // the mover sort and the merge (see nrs_kernels_resort.h)
+            HIPCHK(hipEventSynchronize(rsEvent));
+            const uint32_t M = *(volatile uint32_t *)rsHostTotal;
+            ++rsSteps;
+            if ((uint64_t)M * RESORT_MAX_MOVER_DIV <= (uint64_t)N) {
+                if (M == 0) {
+                    merged = rsStayers.as<uint64_t>();
+                } else {
+                    rocprim::double_buffer<uint64_t> mk(rsMovers.as<uint64_t>(), rsMoversAlt.as<uint64_t>());
+                    size_t tmp = sortTmp.bytes;
+                    HIPCHK(sort_movers(sortTmp.p, tmp, mk, (size_t)M, sort_end_bit(), stream));
+                    tmp = sortTmp.bytes;
+                    HIPCHK(rocprim::merge(sortTmp.p, tmp, rsStayers.as<uint64_t>(), mk.current(), rsMerged.as<uint64_t>(), (size_t)(N - M),
+                                          (size_t)M, rocprim::less<uint64_t>(), stream));
+                    merged = rsMerged.as<uint64_t>();
+                }
+            } else {
+                ++rsFallbacks;
+            }
+        }
+        if (!merged) {
+            rocprim::double_buffer<uint32_t> k(kIn, kAlt);
+            rocprim::double_buffer<uint32_t> v(vIn, vAlt);
+            size_t tmp = sortTmp.bytes;
+            HIPCHK(sort_pairs(sortTmp.p, tmp, k, v, (size_t)N, sort_end_bit(), stream));
+            hashCur = k.current(); indexCur = v.current();
+        } else {
+            hashCur = kAlt; indexCur = vAlt; // plain sorted arrays, written by k_reorder_merged below
+        }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_SORT) return NRS_OK;
 
         NRSCHK(ev_begin(NRS_STAGE_REORDER));
         if (!cellsClean) HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
         cellsClean = false;
-        hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
-                           iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
-                           cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
+        if (merged)
+            hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
+                               iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
+                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
+        else
+            hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
+                               iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
+                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
         NRSCHK(ev_end());
         return NRS_OK;
     }
@@ -494,11 +579,27 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             fo.newPos = posA.as<T4>(); fo.newVel = velA.as<T4>();
             fo.hash = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
             fo.index = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+            const bool resort = rsMovers.p && !slabOn && (uint64_t)N >= RESORT_MIN_PARTICLES;
+            fo.prevHash = resort ? hashCur : nullptr;
+            fo.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
                                                       velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
             hashNext = fo.hash; indexNext = fo.index;
             hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
             fusedThisStep = true;
+            if (resort) {
+                NRSCHK(ev_end());
+                NRSCHK(ev_begin(NRS_STAGE_SORT)); // first half of the next step's sort: scan of the tile counts + split
+                const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+                uint32_t *sc = rsScalars.as<uint32_t>();
+                hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
+                                   rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
+                                   (volatile uint32_t *)rsHostTotalDev, nTiles);
+                HIPCHK(hipEventRecord(rsEvent, stream));
+                hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, rsTileOffset.as<uint32_t>(),
+                                   rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                rsPending = true;
+            }
         } else {
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
                                                       velB.as<T4>(), dens.as<R>(), presB.as<R>(), forces.as<T4>(),
@@ -721,6 +822,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    void resort_stats(uint64_t *steps, uint64_t *fallbacks) override
+    {
+        if (steps) *steps = rsSteps;
+        if (fallbacks) *fallbacks = rsFallbacks;
+    }
     int step(int nsteps, int stop) override
     {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
@@ -993,6 +1099,12 @@ int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32
 {
     CTX_GUARD(ctx);
     return ctx->impl->slab_histogram(first_cell, ncells, counts);
+}
+int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks)
+{
+    CTX_GUARD(ctx);
+    ctx->impl->resort_stats(steps, fallbacks);
+    return NRS_OK;
 }
 uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision) { return 16 + capacity * 2 * (precision == 64 ? 32 : 16); }
 

@@ -1,0 +1,140 @@
+// nrs_kernels_resort.h — coherent re-sort of the (hash, index) pairs between two steps.
+//
+// The reference sorts all pairs from scratch every step (thrust::sort_by_key, sph_cuda.cu:310-313).  Between two
+// steps only a few per cent of the particles change grid cell (CFL: < 1 cell per step; measured 0.3-7 % over the
+// first 400 steps of the 1 M dam-break), and the arrays are still in the previous step's sorted order.  With
+// k_i = next hash of the particle in sorted slot i, the stable sort by (k_i, i) is therefore a MERGE of
+//   stayers  (k_i == previous hash of slot i): already sorted, because their keys are the previous sorted keys,
+//   movers   (k_i != previous hash):           few; sorted on their own with a radix sort.
+// Pairs travel as one u64 "hash << 32 | slot" so that the merge order IS the stable-sort order (no ties); the
+// result is identical to the full stable radix sort, element for element.
+//
+//   k_forces_*  (fused epilogue)   counts the movers of every 256-slot tile            → tileMovers[tile]
+//   k_resort_scan_tiles            exclusive scan of the tile counts, total to the host → tileOffset[], *total
+//   k_resort_split                 stable two-way compaction into movers[] / stayers[]
+//   rocprim::radix_sort_keys       movers only (bits 32 .. 32+log2(numCells))
+//   rocprim::merge                 stayers + movers → merged[]
+//   k_reorder_merged               cell ranges + gather from merged[], also leaves plain hash[] / index[] arrays
+// The host needs the mover count to size the last two calls: it is read after the split has been queued, so the
+// copy overlaps the split and the cell-table reset; above N/8 movers the step falls back to the full radix sort.
+#pragma once
+#include "nrs_kernels_ref.h"
+
+namespace nrs {
+
+constexpr int RESORT_GROUP = 1024;              // tiles per scan workgroup
+constexpr uint64_t RESORT_MIN_PARTICLES = 32768; // below this the full sort is launch-bound either way
+constexpr uint64_t RESORT_MAX_MOVER_DIV = 8;     // more than N/8 movers: full radix sort
+
+// Exclusive scan of the per-tile mover counts, two levels: every workgroup scans RESORT_GROUP counts (coalesced; the
+// counts are reset to 0 for the next step's atomics) and the last one to finish scans the group totals.
+// tileOffset[t] is local to the group; groupPrefix[t / RESORT_GROUP] is added by the consumer.
+__global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__restrict__ tileMovers,
+                                                                     uint32_t *__restrict__ tileOffset,
+                                                                     uint32_t *__restrict__ groupTotal,
+                                                                     uint32_t *__restrict__ groupPrefix, uint32_t *__restrict__ done,
+                                                                     uint32_t *__restrict__ total, volatile uint32_t *hostTotal,
+                                                                     uint32_t nTiles)
+{
+    __shared__ uint32_t waveSum[RESORT_GROUP / 64];
+    __shared__ bool last;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    auto block_exclusive = [&](uint32_t v, uint32_t &sum) { // exclusive prefix of v over the workgroup, sum = total
+        uint32_t inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        __syncthreads();
+        if (lane == 63) waveSum[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0, all = 0;
+        for (uint32_t w = 0; w < RESORT_GROUP / 64; ++w) { const uint32_t c = waveSum[w]; if (w < wave) base += c; all += c; }
+        sum = all;
+        return base + inc - v;
+    };
+    const uint32_t t = blockIdx.x * RESORT_GROUP + tid;
+    uint32_t v = 0;
+    if (t < nTiles) { v = tileMovers[t]; tileMovers[t] = 0; }
+    uint32_t sum;
+    const uint32_t ex = block_exclusive(v, sum);
+    if (t < nTiles) tileOffset[t] = ex;
+    if (tid == 0) {
+        groupTotal[blockIdx.x] = sum;
+        __threadfence();
+        last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // gridDim.x <= RESORT_GROUP (checked by the host): one more scan over the group totals
+    const uint32_t g = tid < gridDim.x ? __atomic_load_n(&groupTotal[tid], __ATOMIC_RELAXED) : 0u;
+    uint32_t all;
+    const uint32_t gex = block_exclusive(g, all);
+    if (tid < gridDim.x) groupPrefix[tid] = gex;
+    if (tid == 0) {
+        *total = all;
+        if (hostTotal) *hostTotal = all;
+        *done = 0;
+    }
+}
+
+// stable split of slot i (tile = i / BLOCK) by "hash changed": movers[rank among movers], stayers[rank among stayers]
+__global__ __launch_bounds__(BLOCK) void k_resort_split(const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash,
+                                                        const uint32_t *__restrict__ tileOffset,
+                                                        const uint32_t *__restrict__ groupPrefix, uint64_t *__restrict__ movers,
+                                                        uint64_t *__restrict__ stayers, uint32_t n)
+{
+    __shared__ uint32_t waveCount[BLOCK / 64];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t i = tile * BLOCK + tid;
+    const bool live = i < n;
+    uint32_t k = 0;
+    bool mover = false;
+    if (live) { k = nextHash[i]; mover = k != prevHash[i]; }
+    const uint64_t mask = __ballot(mover);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0) waveCount[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) before += waveCount[w];
+    if (!live) return;
+    const uint32_t moversBefore = groupPrefix[tile / RESORT_GROUP] + tileOffset[tile] + before;
+    const uint64_t e = ((uint64_t)k << 32) | i;
+    if (mover) movers[moversBefore] = e;
+    else stayers[i - moversBefore] = e;
+}
+
+// reorderDataAndFindCellStartD (sph_kernel_impl.cuh:210-281) fed by the merged u64 pairs; also writes the plain
+// sorted hash / index arrays the rest of the step (and nrs_get_array) use.
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__restrict__ merged, uint32_t *__restrict__ hashOut,
+                                                          uint32_t *__restrict__ indexOut,
+                                                          const typename Vec4T<R>::type *__restrict__ oldPos,
+                                                          const typename Vec4T<R>::type *__restrict__ oldVel,
+                                                          const R *__restrict__ oldPres,
+                                                          typename Vec4T<R>::type *__restrict__ sPos,
+                                                          typename Vec4T<R>::type *__restrict__ sVel, R *__restrict__ sPres,
+                                                          uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
+                                                          uint32_t *__restrict__ inv, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = merged[i];
+    const uint32_t h = (uint32_t)(e >> 32), src = (uint32_t)e;
+    if (i == 0) {
+        cellStart[h] = 0;
+    } else {
+        const uint32_t hp = (uint32_t)(merged[i - 1] >> 32);
+        if (h != hp) { cellStart[h] = i; cellEnd[hp] = i; }
+    }
+    if (i == n - 1) cellEnd[h] = n;
+    hashOut[i] = h;
+    indexOut[i] = src;
+    sPos[i] = oldPos[src];
+    sVel[i] = oldVel[src];
+    if (oldPres) sPres[i] = oldPres[src];
+    if (inv) inv[src] = i;
+}
+
+} // namespace nrs

@@ -375,6 +375,10 @@ template <typename R> struct FusedOut {
     typedef typename Vec4T<R>::type T4;
     T4 *newPos, *newVel;    // next step's "unsorted" arrays
     uint32_t *hash, *index; // next step's keys / values
+    // coherent re-sort (nrs_kernels_resort.h): this step's sorted keys and the per-tile count of slots whose key
+    // changes; both null when the next step sorts from scratch
+    const uint32_t *prevHash;
+    uint32_t *tileMovers;
 };
 
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
@@ -391,8 +395,10 @@ NRS_DEV void forces_epilogue(const Params<R> &P, typename Vec4T<R>::type p4, typ
         fo.newPos[i] = mk4<R>(pn, p4.w);
         fo.newVel[i] = mk4<R>(v, v4.w);
         const I3 g = calcGridPos<R>(P, pn);
-        fo.hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
+        const uint32_t h = calcGridHash<R>(P, g.x, g.y, g.z);
+        fo.hash[i] = h;
         fo.index[i] = i;
+        if (fo.tileMovers && h != fo.prevHash[i]) atomicAdd(&fo.tileMovers[i / BLOCK], 1u);
     }
 }
 
@@ -510,6 +516,8 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     FusedOut<R> fo;
     fo.newPos = fo.newVel = nullptr;
     fo.hash = fo.index = nullptr;
+    fo.prevHash = nullptr;
+    fo.tileMovers = nullptr;
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     if (lists) {

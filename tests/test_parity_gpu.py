@@ -208,6 +208,56 @@ def test_kernel_path_flags_are_bitwise_equivalent(hip_lib):
             np.testing.assert_array_equal(a, b)
 
 
+def test_coherent_resort_equals_full_sort(hip_lib):
+    """Default path (sort only the particles that changed cell, merge into the rest) vs NRS_FLAG_FULL_SORT (the
+    reference's sort-everything): identical hash / index / cell tables / state after every checked step, the oracle's
+    hash and index bit for bit, and the fall-back when most particles change cell."""
+    p, sc = small_dam_break((40, 36, 32))
+    n = len(sc["pos"])
+    assert n >= 32768  # below that the context always sorts from scratch
+    names = ("hash", "index", "cellStart", "cellEnd", "dens")
+    solvers = []
+    for flags in (0, capi.FLAG_FULL_SORT):
+        s = capi.Solver(p, n, flags=flags)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        solvers.append(s)
+    o = Oracle(p, solver=SESPH, threads=min(16, os.cpu_count() or 1))
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    done = 0
+    for k in (1, 2, 5, 12, 20):
+        for s in solvers:
+            s.step(k)
+        done += k
+        a, b = [s.download() + tuple(s.get(x) for x in names) for s in solvers]
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        if done <= 8:
+            o.step(k)
+            np.testing.assert_array_equal(a[2], o.get("hash"))
+            np.testing.assert_array_equal(a[3], o.get("index"))
+    steps, fallbacks = solvers[0].resort_stats()
+    assert steps == done - 1 and fallbacks == 0   # the step after an upload sorts from scratch
+    assert solvers[1].resort_stats() == (0, 0)
+    # most particles change cell in one step: the count exceeds N/8 and the step sorts from scratch
+    h = float(p["interactionRadius"][0])
+    dt = float(p["timestep"][0])
+    rng = np.random.default_rng(5)
+    pos = solvers[0].download()[0]
+    vel = np.zeros_like(pos)
+    vel[:, :3] = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32) * (0.9 * h / dt)
+    for s in solvers:
+        s.set_particles(pos, vel)
+        s.step(3)
+    a, b = [s.download() + tuple(s.get(x) for x in names) for s in solvers]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert solvers[0].resort_stats()[1] >= 1
+    for s in solvers:
+        s.close()
+
+
 def test_edge_cases(hip_lib):
     p = Oracle.default_params(SESPH)
     # empty: stepping an empty solver is a no-op
