@@ -262,6 +262,7 @@ def main():
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
             "kernels": "reference-order" if args.reference_order else "tiled",
+            "sort": dict(zip(("coherent_resort_steps", "fell_back_to_full_sort"), s.resort_stats())),
             "parallelism": "1 GPU",
         },
         "roofline": {

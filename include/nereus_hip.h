@@ -207,9 +207,10 @@ int nrs_last_iterations(nrs_ctx *ctx, uint32_t *iters);
 int nrs_set_max_iterations(nrs_ctx *ctx, uint32_t max_iters);
 
 /* Per-stage device time, measured with HIP events recorded on the context's stream around the stage's
- * launches.  stage_mask: bit s set = time NRS_STAGE_s (0 = off, 0xffffffff = every stage).  nrs_stage_ms
- * returns the time of that stage summed over the steps of the LAST nrs_step call, and how many launches
- * of the stage that covers. */
+ * launches.  stage_mask: bit s set = time NRS_STAGE_s (0 = off, 0xffffffff = every stage).  nrs_set_profiling also
+ * resets the accumulated times.  nrs_stage_ms returns the time of that stage summed over all steps since the last
+ * nrs_set_profiling call and how many launches of the stage that covers; it synchronizes the stream (nrs_step itself
+ * does not: event pairs are resolved lazily). */
 int nrs_set_profiling(nrs_ctx *ctx, uint32_t stage_mask);
 int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches);
 

@@ -245,7 +245,7 @@ class Solver:
         self._chk(self.lib.nrs_set_profiling(self.h, mask))
 
     def stage_ms(self):
-        """{stage name: (ms summed over the last nrs_step call, launches)}"""
+        """{stage name: (ms summed over the steps since the last set_profiling call, launches)}; synchronizes"""
         out = {}
         for sid, name in STAGE_NAMES.items():
             ms, cnt = C.c_float(0), C.c_uint32(0)

@@ -127,6 +127,7 @@ struct CtxBase {
     virtual uint64_t num_owned() = 0;
     virtual int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) = 0;
     virtual void resort_stats(uint64_t *steps, uint64_t *fallbacks) = 0;
+    virtual int set_profiling(uint32_t mask) = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     int device = 0;
@@ -156,8 +157,12 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf redPartial, redOut;
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
     // coherent re-sort (nrs_kernels_resort.h)
-    DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars;
-    uint32_t *rsHostTotal = nullptr, *rsHostTotalDev = nullptr; // mover count, written by k_resort_scan_tiles (pinned, mapped)
+    DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars, rsPrevPacked;
+    bool slotOrderValid = false; // posA/velA are in the slot order of hashCur (a full fused step was the last thing that happened)
+    uint32_t *packKeys = nullptr, *packVals = nullptr; // where slab_pack / slab_unpack write the next step's keys / values
+    uint64_t *rsHostTotal = nullptr, *rsHostTotalDev = nullptr; // (launch number << 32 | mover count), written by
+                                                                // k_resort_scan_tiles into pinned, mapped host memory
+    uint32_t rsSeq = 0;
     hipEvent_t rsEvent = nullptr;
     bool rsPending = false; // movers/stayers of the keys in hashNext have been split; the count is on its way
     uint64_t rsSteps = 0, rsFallbacks = 0;
@@ -169,6 +174,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     uint32_t ghostCount = 0;
     bool cellsClean = false; // cellStart is all-EMPTY
     bool packedHashValid = false;
+    bool packResort = false; // this pack compacted the previous sorted keys next to the new ones
+    uint32_t packChanged = 0; // ... and counted the owned particles that stay but changed cell
+    bool rsCountKnown = false; // the mover count of the pending split is already on the host (slab runs)
+    uint32_t rsKnownCount = 0;
     bool fusedThisStep = false;
     // profiling
     struct Ev { int stage; hipEvent_t a, b; bool cont; };
@@ -195,7 +204,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
                          &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
-                         &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars};
+                         &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked};
         for (DevBuf *b : all) b->release();
         if (rsEvent) (void)hipEventDestroy(rsEvent);
         if (rsHostTotal) (void)hipHostFree(rsHostTotal);
@@ -268,9 +277,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(rsMovers.alloc(8 * cap)); NRSCHK(rsMoversAlt.alloc(8 * mcap)); NRSCHK(rsStayers.alloc(8 * cap)); NRSCHK(rsMerged.alloc(8 * cap));
             NRSCHK(rsTileMovers.alloc(4 * nTiles)); NRSCHK(rsTileOffset.alloc(4 * nTiles));
             NRSCHK(rsGroupTotal.alloc(4 * nGroups)); NRSCHK(rsGroupPrefix.alloc(4 * nGroups)); NRSCHK(rsScalars.alloc(8));
+            NRSCHK(rsPrevPacked.alloc(4 * cap));
             HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, 4 * nTiles, stream));
             HIPCHK(hipMemsetAsync(rsScalars.p, 0, 8, stream));
             HIPCHK(hipHostMalloc((void **)&rsHostTotal, 64, hipHostMallocMapped));
+            std::memset(rsHostTotal, 0, 64);
             HIPCHK(hipHostGetDevicePointer((void **)&rsHostTotalDev, rsHostTotal, 0));
             HIPCHK(hipEventCreateWithFlags(&rsEvent, hipEventDisableTiming));
             rocprim::double_buffer<uint64_t> mk(rsMovers.as<uint64_t>(), rsMoversAlt.as<uint64_t>());
@@ -294,7 +305,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         Params<R> q;
         std::memcpy(&q, params, sizeof(q));
         const bool regrid = q.numCells != P.numCells;
-        if (std::memcmp(&P, &q, sizeof(P)) != 0) hashReady = false; // grid/origin may have changed: re-hash
+        if (std::memcmp(&P, &q, sizeof(P)) != 0) { hashReady = false; slotOrderValid = false; } // grid/origin may have changed: re-hash
         P = q;
         if (regrid) {
             NRSCHK(alloc_cells());
@@ -323,12 +334,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (first + count > n) n = first + count;
         midStep = false;
         hashReady = false;
+        slotOrderValid = false;
         return NRS_OK;
     }
     int set_n(uint64_t nn) override
     {
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
-        if (nn != n) hashReady = false;
+        if (nn != n) { hashReady = false; slotOrderValid = false; }
         n = nn;
         return NRS_OK;
     }
@@ -434,9 +446,17 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         ++evUsed;
         return NRS_OK;
     }
+    int set_profiling(uint32_t mask) override
+    {
+        NRSCHK(ev_collect());
+        profMask = mask;
+        std::memset(stageMs, 0, sizeof(stageMs));
+        std::memset(stageLaunches, 0, sizeof(stageLaunches));
+        return NRS_OK;
+    }
     int ev_collect()
     {
-        if (!profMask || !evUsed) return NRS_OK;
+        if (!evUsed) return NRS_OK;
         HIPCHK(hipStreamSynchronize(stream));
         for (size_t i = 0; i < evUsed; ++i) {
             float ms = 0;
@@ -450,6 +470,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int stage_ms(int stage, float *ms, uint32_t *launches) override
     {
         if (stage < 0 || stage >= NRS_STAGE_COUNT) return fail(NRS_E_INVALID, "bad stage");
+        NRSCHK(ev_collect()); // resolves the pending event pairs (synchronizes the stream)
         *ms = stageMs[stage];
         if (launches) *launches = stageLaunches[stage];
         return NRS_OK;
@@ -495,6 +516,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const bool resort = hashReady && rsPending && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT;
         hashReady = false;
         rsPending = false;
+        rsCountKnown = false;
         hashCur = kIn; indexCur = vIn;
         if (stop == NRS_STAGE_HASH) return NRS_OK;
 
@@ -503,8 +525,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (resort) {
             // the split of these keys into movers / stayers was queued behind the force kernel; its mover count sizes
             // the mover sort and the merge (see nrs_kernels_resort.h)
-            HIPCHK(hipEventSynchronize(rsEvent));
-            const uint32_t M = *(volatile uint32_t *)rsHostTotal;
+            uint32_t M = rsKnownCount;
+            if (!rsCountKnown) NRSCHK(wait_mover_count(&M));
             ++rsSteps;
             if ((uint64_t)M * RESORT_MAX_MOVER_DIV <= (uint64_t)N) {
                 if (M == 0) {
@@ -594,7 +616,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 uint32_t *sc = rsScalars.as<uint32_t>();
                 hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
                                    rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
-                                   (volatile uint32_t *)rsHostTotalDev, nTiles);
+                                   (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
                 HIPCHK(hipEventRecord(rsEvent, stream));
                 hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, rsTileOffset.as<uint32_t>(),
                                    rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
@@ -746,19 +768,29 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
         const uint32_t N = (uint32_t)n;
         const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_TILE - 1) / SLAB_TILE);
-        NRSCHK(slabCounts.alloc((size_t)ST_COUNT * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
-        NRSCHK(slabTotals.alloc(ST_COUNT * 4));
+        NRSCHK(slabCounts.alloc((size_t)ST_TOTALS * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
+        NRSCHK(slabTotals.alloc(ST_TOTALS * 4));
         NRSCHK(ghostPos.alloc(sizeof(T4) * cap));
         NRSCHK(ghostVel.alloc(sizeof(T4) * cap));
-        uint32_t tot[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+        uint32_t tot[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
         if (N) {
+            // coherent re-sort of the next step: possible when the arrays are still in the slot order of the last sort and
+            // the fused force kernel left the new keys per slot
+            const bool resort = rsMovers.p && slotOrderValid && hashCur && hashNext && hashNext != hashCur;
             hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
-                               slabCounts.as<uint32_t>(), nbk);
-            hipLaunchKernelGGL(k_slab_scan, dim3(ST_COUNT), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
+                               slabCounts.as<uint32_t>(), nbk, resort ? hashCur : (const uint32_t *)nullptr,
+                               resort ? hashNext : (const uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_slab_scan, dim3(ST_TOTALS), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
                                slabTotals.as<uint32_t>());
             SlabOut<R> out;
             out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
-            out.hash = hashA.as<uint32_t>(); out.index = indexA.as<uint32_t>(); // the hash pass of the next step, done here
+            // the hash pass of the next step, done here (into the key buffers the last sort did not end in)
+            packKeys = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+            packVals = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+            out.hash = packKeys; out.index = packVals;
+            out.prevHash = resort ? hashCur : nullptr;
+            out.prevPacked = resort ? rsPrevPacked.as<uint32_t>() : nullptr;
+            packResort = resort;
             out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
             out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
             out.cap = (uint32_t)cap;
@@ -770,7 +802,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             HIPCHK(hipMemcpyAsync(tot, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
         } else {
-            HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_COUNT * 4, stream));
+            HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_TOTALS * 4, stream));
             hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
                                (unsigned char *)sendR);
             HIPCHK(hipStreamSynchronize(stream));
@@ -778,12 +810,16 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if ((uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > cap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > cap || tot[ST_GHOST] > cap)
             return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
         if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
+        else { packKeys = hashA.as<uint32_t>(); packVals = indexA.as<uint32_t>(); packResort = false; }
         hashReady = false;
+        rsPending = false;
+        slotOrderValid = false;
         packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];
-        if (counts) std::memcpy(counts, tot, sizeof(tot));
+        packChanged = tot[ST_CHANGED];
+        if (counts) std::memcpy(counts, tot, ST_COUNT * sizeof(uint32_t));
         return NRS_OK;
     }
     uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_TILE - 1) / SLAB_TILE); }
@@ -812,16 +848,55 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         for (int k = 0; k < 5; ++k) A.start[k + 1] = A.start[k] + len[k];
         if (A.start[5])
             hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, P, A,
-                               posA.as<T4>(), velA.as<T4>(), hashA.as<uint32_t>(), indexA.as<uint32_t>(), (uint32_t)n);
+                               posA.as<T4>(), velA.as<T4>(), packKeys, packVals, packResort ? rsPrevPacked.as<uint32_t>() : (uint32_t *)nullptr,
+                               (uint32_t)n);
         HIPCHK(hipGetLastError());
         nOwned = n + hL[0] + hR[0];
         n = total;
         // pack + unpack have written the radix keys/values of every local particle
-        hashNext = hashA.as<uint32_t>(); indexNext = indexA.as<uint32_t>();
+        hashNext = packKeys; indexNext = packVals;
         hashReady = packedHashValid;
+        if (hashReady && packResort && n >= RESORT_MIN_PARTICLES) {
+            // coherent re-sort: the owned particles that stayed in their cell are still in sorted order
+            const uint32_t N = (uint32_t)n, nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+            uint32_t *sc = rsScalars.as<uint32_t>();
+            hipLaunchKernelGGL(k_resort_count, dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
+                               rsTileMovers.as<uint32_t>(), N);
+            hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
+                               rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
+                               (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
+            HIPCHK(hipEventRecord(rsEvent, stream));
+            hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
+                               rsTileOffset.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+            rsPending = true;
+            rsCountKnown = true; // everything appended is a mover, and the partition counted the cell changers
+            rsKnownCount = packChanged + A.start[5];
+        }
+        packResort = false;
         return NRS_OK;
     }
 
+    // The scan kernel stores (launch number, count) straight into mapped host memory; polling that word costs a PCIe
+    // write latency, where hipEventSynchronize on an otherwise idle host thread was measured to cost ~0.1 ms per step.
+    int wait_mover_count(uint32_t *M)
+    {
+        static const bool poll = !(getenv("NEREUS_RS_POLL") && atoi(getenv("NEREUS_RS_POLL")) == 0);
+        volatile uint64_t *w = (volatile uint64_t *)rsHostTotal;
+        if (poll) {
+            for (uint64_t spins = 0;; ++spins) {
+                const uint64_t v = *w;
+                if ((uint32_t)(v >> 32) == rsSeq) { *M = (uint32_t)v; return NRS_OK; }
+                if ((spins & 0xfffff) == 0xfffff) { // every ~1 M polls: has the stream failed or finished without us seeing it?
+                    const hipError_t e = hipEventQuery(rsEvent);
+                    if (e == hipSuccess) break;
+                    if (e != hipErrorNotReady) HIPCHK(e);
+                }
+            }
+        }
+        HIPCHK(hipEventSynchronize(rsEvent));
+        *M = (uint32_t)*w;
+        return NRS_OK;
+    }
     void resort_stats(uint64_t *steps, uint64_t *fallbacks) override
     {
         if (steps) *steps = rsSteps;
@@ -831,7 +906,6 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
         if (n == 0) return NRS_OK;
-        if (profMask) { std::memset(stageMs, 0, sizeof(stageMs)); std::memset(stageLaunches, 0, sizeof(stageLaunches)); }
         for (int s = 0; s < nsteps; ++s) {
             fusedThisStep = false;
             NRSCHK(stage_prefix(stop));
@@ -845,6 +919,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 cellsClean = true;
             }
             // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
+            slotOrderValid = fusedThisStep; // A holds the new state in the slot order of hashCur
             if (!fusedThisStep) { // the fused kernel already wrote the new state into A
                 std::swap(posA.p, posB.p);
                 std::swap(velA.p, velB.p);
@@ -852,7 +927,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             if (iisph()) std::swap(presA.p, presB.p);
         }
         HIPCHK(hipGetLastError());
-        NRSCHK(ev_collect());
+        if (evUsed > 8192) NRSCHK(ev_collect()); // bound the pool of pending event pairs
         return NRS_OK;
     }
     int sync() override
@@ -1070,8 +1145,7 @@ int nrs_set_max_iterations(nrs_ctx *ctx, uint32_t max_iters)
 int nrs_set_profiling(nrs_ctx *ctx, uint32_t stage_mask)
 {
     CTX_GUARD(ctx);
-    ctx->impl->profMask = stage_mask;
-    return NRS_OK;
+    return ctx->impl->set_profiling(stage_mask);
 }
 int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches)
 {

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__
                                                                      uint32_t *__restrict__ tileOffset,
                                                                      uint32_t *__restrict__ groupTotal,
                                                                      uint32_t *__restrict__ groupPrefix, uint32_t *__restrict__ done,
-                                                                     uint32_t *__restrict__ total, volatile uint32_t *hostTotal,
-                                                                     uint32_t nTiles)
+                                                                     uint32_t *__restrict__ total, volatile uint64_t *hostTotal,
+                                                                     uint32_t seq, uint32_t nTiles)
 {
     __shared__ uint32_t waveSum[RESORT_GROUP / 64];
     __shared__ bool last;
@@ -74,9 +74,20 @@ __global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__
     if (tid < gridDim.x) groupPrefix[tid] = gex;
     if (tid == 0) {
         *total = all;
-        if (hostTotal) *hostTotal = all;
+        if (hostTotal) *hostTotal = ((uint64_t)seq << 32) | all; // one 8-byte store to mapped host memory: (launch number, count)
         *done = 0;
     }
+}
+
+// movers per tile when no force kernel counted them (slab runs: the arrays were re-partitioned in between; prevHash
+// is 0xffffffff for slots that were appended, so they always count as movers)
+__global__ __launch_bounds__(BLOCK) void k_resort_count(const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash,
+                                                        uint32_t *__restrict__ tileMovers, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool mover = i < n && prevHash[i] != nextHash[i];
+    const uint64_t mask = __ballot(mover);
+    if ((threadIdx.x & 63u) == 0 && mask) atomicAdd(&tileMovers[blockIdx.x], (uint32_t)__popcll(mask));
 }
 
 // stable split of slot i (tile = i / BLOCK) by "hash changed": movers[rank among movers], stayers[rank among stayers]

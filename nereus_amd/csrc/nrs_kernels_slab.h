@@ -20,7 +20,9 @@
 
 namespace nrs {
 
-enum { ST_STAY = 0, ST_MIG_L = 1, ST_HALO_L = 2, ST_MIG_R = 3, ST_HALO_R = 4, ST_GHOST = 5, ST_COUNT = 6 };
+enum { ST_STAY = 0, ST_MIG_L = 1, ST_HALO_L = 2, ST_MIG_R = 3, ST_HALO_R = 4, ST_GHOST = 5, ST_COUNT = 6,
+       ST_CHANGED = 6,  // counted only (no output stream): STAY particles whose grid cell changed in the last step
+       ST_TOTALS = 7 };
 constexpr int SLAB_BLOCK = 256;
 constexpr int SLAB_ITERS = 8;                       // sub-tiles per workgroup: 2048 particles per workgroup keeps the block-
 constexpr int SLAB_TILE = SLAB_BLOCK * SLAB_ITERS;  // offset scan short (it was the most expensive slab kernel at 256)
@@ -49,21 +51,25 @@ template <typename R> NRS_DEV uint32_t slab_flags(const Params<R> &P, const Slab
 // pass 1: per-workgroup population of every stream
 template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
-                                                          uint32_t n, uint32_t *__restrict__ blockCounts, uint32_t nBlocks)
+                                                          uint32_t n, uint32_t *__restrict__ blockCounts, uint32_t nBlocks,
+                                                          const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash)
 {
-    __shared__ uint32_t cnt[ST_COUNT];
-    if (threadIdx.x < ST_COUNT) cnt[threadIdx.x] = 0;
+    // prevHash / nextHash (both or neither): sorted keys of the last step and the keys its fused force kernel computed
+    // for the new positions, per slot — lets the host know how many particles the coherent re-sort has to sort
+    __shared__ uint32_t cnt[ST_TOTALS];
+    if (threadIdx.x < ST_TOTALS) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (int it = 0; it < SLAB_ITERS; ++it) {
         const uint32_t i = blockIdx.x * SLAB_TILE + it * SLAB_BLOCK + threadIdx.x;
-        const uint32_t f = i < n ? slab_flags<R>(P, c, pos[i]) : 0u;
-        for (int s = 0; s < ST_COUNT; ++s) {
+        uint32_t f = i < n ? slab_flags<R>(P, c, pos[i]) : 0u;
+        if (prevHash && (f & (1u << ST_STAY)) && prevHash[i] != nextHash[i]) f |= 1u << ST_CHANGED;
+        for (int s = 0; s < ST_TOTALS; ++s) {
             const unsigned long long m = __ballot((f >> s) & 1u);
             if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[s], (uint32_t)__popcll(m));
         }
     }
     __syncthreads();
-    if (threadIdx.x < ST_COUNT) blockCounts[threadIdx.x * nBlocks + blockIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < ST_TOTALS) blockCounts[threadIdx.x * nBlocks + blockIdx.x] = cnt[threadIdx.x];
 }
 
 // pass 2: exclusive scan of the block counts, one workgroup per stream; totals[s] = stream population
@@ -99,6 +105,8 @@ template <typename R> struct SlabOut {
     typedef typename Vec4T<R>::type T4;
     T4 *stayPos, *stayVel;   // compacted owned particles
     uint32_t *hash, *index;  // radix-sort keys/values of the next step for the compacted particles (saves a hash pass)
+    const uint32_t *prevHash; // sorted keys of the step that produced `pos` (slot order), or null
+    uint32_t *prevPacked;     // their compacted copy for the coherent re-sort (nrs_kernels_resort.h), or null
     T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
     unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
     uint32_t cap;            // particles per message buffer
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
                     const I3 g = calcGridPos<R>(P, xyz<R>(p));
                     out.hash[idx] = calcGridHash<R>(P, g.x, g.y, g.z);
                     out.index[idx] = idx;
+                    if (out.prevPacked) out.prevPacked[idx] = out.prevHash ? out.prevHash[i] : 0xffffffffu;
                     break;
                 }
                 case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
@@ -212,7 +221,8 @@ template <typename R> struct AppendPieces {
 template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
                                                            typename Vec4T<R>::type *__restrict__ dstVel, uint32_t *__restrict__ hash,
-                                                           uint32_t *__restrict__ index, uint32_t dstBase)
+                                                           uint32_t *__restrict__ index, uint32_t *__restrict__ prevPacked,
+                                                           uint32_t dstBase)
 {
     const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (i >= A.start[5]) return;
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendP
     const I3 g = calcGridPos<R>(P, xyz<R>(p));
     hash[dstBase + i] = calcGridHash<R>(P, g.x, g.y, g.z);
     index[dstBase + i] = dstBase + i;
+    if (prevPacked) prevPacked[dstBase + i] = 0xffffffffu; // new to this rank's arrays: never a "stayer"
 }
 
 } // namespace nrs

@@ -27,7 +27,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0):
+def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0, lattice=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -37,9 +37,10 @@ def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    p, cuts, pos, vel, bi, vbi, info = slab.rank_scene(LATTICE, rank, world, default_params(0))
+    lattice = lattice or LATTICE
+    p, cuts, pos, vel, bi, vbi, info = slab.rank_scene(lattice, rank, world, default_params(0))
     # particle id rides in vel.w (preserved by reorder/integrate/exchange): global lattice id
-    nx, ny, nz = LATTICE
+    nx, ny, nz = lattice
     d = float(np.float32(p["interactionRadius"][0])) - 0.005
     ix = np.rint(pos[:, 0] / d - 1).astype(np.int64)
     iy = np.rint(pos[:, 1] / d - 1).astype(np.int64)
@@ -61,9 +62,11 @@ def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0
         vel[:, 0] = np.where((iy + iz) % 2 == 0, 2.5, -2.5).astype(np.float32)
         full_scene = scene.dam_break((nx * world, ny, nz), h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
         bi, vbi = full_scene["bi"], full_scene["vbi"]  # every rank sees the whole (small) tank: cuts will move
-    msg_cap = 4096
+    msg_cap, ctx_cap = 4096, 8192
+    if lattice != LATTICE:
+        msg_cap, ctx_cap = slab.capacities(lattice, float(p["interactionRadius"][0]), len(pos))
     if use_hip:
-        eng = slab.HipSlabEngine(p, 8192, msg_cap, cuts[rank], cuts[rank + 1], 0)
+        eng = slab.HipSlabEngine(p, ctx_cap, msg_cap, cuts[rank], cuts[rank + 1], 0)
     else:
         from tests.slab_check_engine import OracleSlabEngine
 
@@ -82,23 +85,26 @@ def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0
     drv.finish()
     moved += drv.last_counts[1] + drv.last_counts[3]
     op, ov = eng.owned_state()
+    resort = np.array(eng.solver.resort_stats() if use_hip else (0, 0))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), pos=op, vel=ov, moved=moved, cuts=np.array(cuts[1:-1]),
-             params=p.view(np.uint8), owned=np.array(owned_hist))
+             params=p.view(np.uint8), owned=np.array(owned_hist), resort=resort)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, steps, use_hip, tmp_path, skew=0, rebalance_every=0):
+def _run(world, steps, use_hip, tmp_path, skew=0, rebalance_every=0, lattice=None):
     from nereus_amd import scene
     from nereus_amd.params import default_params, params_dtype
     from tests.common import rel_err
     from tests.oracle_lib import SESPH, Oracle
 
-    mp.spawn(_worker, args=(world, _free_port(), steps, use_hip, str(tmp_path), skew, rebalance_every), nprocs=world, join=True)
+    lattice = lattice or LATTICE
+    mp.spawn(_worker, args=(world, _free_port(), steps, use_hip, str(tmp_path), skew, rebalance_every, lattice), nprocs=world,
+             join=True)
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     pos = np.concatenate([q["pos"] for q in parts])
     vel = np.concatenate([q["vel"] for q in parts])
-    nx, ny, nz = LATTICE
+    nx, ny, nz = lattice
     n = nx * world * ny * nz
     assert len(pos) == n, "particles lost or duplicated by the exchange"
     ids = vel[:, 3].astype(np.int64)
@@ -111,7 +117,7 @@ def _run(world, steps, use_hip, tmp_path, skew=0, rebalance_every=0):
     fvel[:, 3] = np.arange(n, dtype=np.float32)
     gid = np.arange(n)
     fvel[:, 0] = np.where(((gid // nz) % ny + gid % nz) % 2 == 0, 2.5, -2.5).astype(np.float32)
-    o = Oracle(p, solver=SESPH)
+    o = Oracle(p, solver=SESPH, threads=min(16, os.cpu_count() or 1))
     o.set_particles(full["pos"], fvel)
     o.set_boundaries(full["bi"], full["vbi"], update_grid=True)
     np.testing.assert_array_equal(o.params.view(np.uint8), p.view(np.uint8))  # same GLOBAL grid on every rank
@@ -122,6 +128,7 @@ def _run(world, steps, use_hip, tmp_path, skew=0, rebalance_every=0):
     assert rel_err(pos[order_got][:, :3], rp[order_ref][:, :3]) <= 1e-5
     assert rel_err(vel[order_got][:, :3], rv[order_ref][:, :3]) <= 1e-5
     _run.owned = [q["owned"] for q in parts]
+    _run.resort = [tuple(int(v) for v in q["resort"]) for q in parts]
     return sum(int(q["moved"]) for q in parts)
 
 
@@ -133,6 +140,19 @@ def test_slab_protocol_gloo_cpu(tmp_path, world):
 @pytest.mark.gpu
 def test_slab_hip_engine_two_ranks_one_gpu(tmp_path, hip_lib):
     assert _run(2, 25, True, tmp_path) > 0
+
+
+@pytest.mark.gpu
+def test_slab_hip_engine_coherent_resort(tmp_path, hip_lib):
+    """Slabs big enough for the coherent re-sort (>= 32768 local particles): after the partition the owned particles
+    that stayed in their cell are merged with the sorted rest (cell changers, arrivals, halo copies) instead of a
+    full sort; same bar against the single-domain oracle, and the path must really have been taken."""
+    steps = 10
+    assert _run(2, steps, True, tmp_path, lattice=(48, 28, 26)) > 0
+    for used, fallbacks in _run.resort:
+        # a fall-back (more than 1/8 of the local particles are cell changers + arrivals + halo copies) is legitimate in
+        # a slab this narrow, but most steps must have merged
+        assert used >= steps - 1 and fallbacks <= used // 3
 
 
 def test_message_capacity_rule_covers_the_halo():

@@ -134,15 +134,16 @@ int main(int argc, char **argv)
     hipEvent_t ev[5];
     for (auto &e : ev) CHK(hipEventCreate(&e));
     const uint32_t nTiles = (n + 255) / 256;
-    uint32_t *dTileMovers, *dTileOffset, *hTotal;
+    uint32_t *dTileMovers, *dTileOffset;
+    uint64_t *hTotal;
     CHK(hipMalloc(&dTileMovers, 4ull * nTiles)); CHK(hipMalloc(&dTileOffset, 4ull * nTiles));
     CHK(hipMemset(dTileMovers, 0, 4ull * nTiles));
     const uint32_t nGroups = (nTiles + nrs::RESORT_GROUP - 1) / nrs::RESORT_GROUP;
     uint32_t *dGroupTotal, *dGroupPrefix, *dDone;
     CHK(hipMalloc(&dGroupTotal, 4ull * nGroups)); CHK(hipMalloc(&dGroupPrefix, 4ull * nGroups)); CHK(hipMalloc(&dDone, 4));
     CHK(hipMemset(dDone, 0, 4));
-    CHK(hipHostMalloc(&hTotal, 4, hipHostMallocMapped));
-    uint32_t *hTotalDev = nullptr;
+    CHK(hipHostMalloc(&hTotal, 8, hipHostMallocMapped));
+    uint64_t *hTotalDev = nullptr;
     CHK(hipHostGetDevicePointer((void **)&hTotalDev, hTotal, 0));
     hipEvent_t evM;
     CHK(hipEventCreateWithFlags(&evM, hipEventDisableTiming));
@@ -151,12 +152,12 @@ int main(int argc, char **argv)
         k_count<<<nTiles, 256, 0, st>>>(dOld, dNext, dTileMovers, n);
         CHK(hipEventRecord(ev[0], st));
         nrs::k_resort_scan_tiles<<<nGroups, nrs::RESORT_GROUP, 0, st>>>(dTileMovers, dTileOffset, dGroupTotal, dGroupPrefix, dDone, dCount,
-                                                                         hTotalDev, nTiles);
+                                                                         hTotalDev, (uint32_t)(r + 1), nTiles);
         CHK(hipEventRecord(evM, st));
         nrs::k_resort_split<<<nTiles, 256, 0, st>>>(dOld, dNext, dTileOffset, dGroupPrefix, dMov, dStay, n);
         CHK(hipEventRecord(ev[1], st));
         CHK(hipEventSynchronize(evM));
-        const uint32_t M = *hTotal;
+        const uint32_t M = (uint32_t)*hTotal;
         if (r == 0) printf("host sees %u movers\n", M);
         rocprim::double_buffer<uint64_t> k(dMov, dMov2);
         if (variant == 0) CHK(rocprim::radix_sort_keys<SortCfg9>(tmp, b, k, M, 32u, 32u + bits, st));
