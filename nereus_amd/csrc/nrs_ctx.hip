@@ -176,6 +176,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool packedHashValid = false;
     bool packResort = false; // this pack compacted the previous sorted keys next to the new ones
     uint32_t packChanged = 0; // ... and counted the owned particles that stay but changed cell
+    bool rsTilesDirty = false; // rsTileMovers holds counts no scan has consumed
+    int clean_tile_counts()
+    {
+        if (rsTilesDirty) HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, rsTileMovers.bytes, stream));
+        rsTilesDirty = false;
+        return NRS_OK;
+    }
     bool rsCountKnown = false; // the mover count of the pending split is already on the host (slab runs)
     uint32_t rsKnownCount = 0;
     bool fusedThisStep = false;
@@ -602,6 +609,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             fo.hash = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
             fo.index = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
             const bool resort = rsMovers.p && !slabOn && (uint64_t)N >= RESORT_MIN_PARTICLES;
+            if (resort) NRSCHK(clean_tile_counts());
             fo.prevHash = resort ? hashCur : nullptr;
             fo.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
@@ -790,6 +798,9 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             out.hash = packKeys; out.index = packVals;
             out.prevHash = resort ? hashCur : nullptr;
             out.prevPacked = resort ? rsPrevPacked.as<uint32_t>() : nullptr;
+            out.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
+            if (resort) NRSCHK(clean_tile_counts());
+            rsTilesDirty = resort;
             packResort = resort;
             out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
             out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
@@ -830,7 +841,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         uint32_t hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
         if (recvL) HIPCHK(hipMemcpyAsync(hL, recvL, 16, hipMemcpyDeviceToHost, stream));
         if (recvR) HIPCHK(hipMemcpyAsync(hR, recvR, 16, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        if (recvL || recvR) HIPCHK(hipStreamSynchronize(stream));
         if ((uint64_t)hL[0] + hL[1] > mcap || (uint64_t)hR[0] + hR[1] > mcap) return fail(NRS_E_INVALID, "corrupt slab message header");
         const uint64_t total = n + hL[0] + hR[0] + ghostCount + hL[1] + hR[1];
         if (total > cap) return fail(NRS_E_CAPACITY, "owned + halo particles exceed the context capacity");
@@ -849,7 +860,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (A.start[5])
             hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, P, A,
                                posA.as<T4>(), velA.as<T4>(), packKeys, packVals, packResort ? rsPrevPacked.as<uint32_t>() : (uint32_t *)nullptr,
-                               (uint32_t)n);
+                               packResort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr, (uint32_t)n);
         HIPCHK(hipGetLastError());
         nOwned = n + hL[0] + hR[0];
         n = total;
@@ -860,8 +871,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             // coherent re-sort: the owned particles that stayed in their cell are still in sorted order
             const uint32_t N = (uint32_t)n, nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
             uint32_t *sc = rsScalars.as<uint32_t>();
-            hipLaunchKernelGGL(k_resort_count, dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
-                               rsTileMovers.as<uint32_t>(), N);
+            // (the partition and the append have counted the movers of every tile of the new arrays)
             hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
                                rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
                                (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
@@ -871,6 +881,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             rsPending = true;
             rsCountKnown = true; // everything appended is a mover, and the partition counted the cell changers
             rsKnownCount = packChanged + A.start[5];
+            rsTilesDirty = false; // the scan resets the counts it reads
         }
         packResort = false;
         return NRS_OK;

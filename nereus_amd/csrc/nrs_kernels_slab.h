@@ -76,27 +76,25 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg 
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scan(uint32_t *__restrict__ blockCounts, uint32_t nBlocks,
                                                           uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t sm[SLAB_BLOCK];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t waveSum[SLAB_BLOCK / 64];
     uint32_t *row = blockCounts + (size_t)blockIdx.x * nBlocks;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < nBlocks; base += SLAB_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < nBlocks ? row[i] : 0u;
-        sm[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < SLAB_BLOCK; off <<= 1) { // Hillis-Steele inclusive scan
-            const uint32_t t = threadIdx.x >= (uint32_t)off ? sm[threadIdx.x - off] : 0u;
-            __syncthreads();
-            sm[threadIdx.x] += t;
-            __syncthreads();
+        uint32_t inc = v; // inclusive scan inside the wave, then across the 4 waves
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += o;
         }
-        const uint32_t incl = sm[threadIdx.x];
-        if (i < nBlocks) row[i] = carry + incl - v;
         __syncthreads();
-        if (threadIdx.x == SLAB_BLOCK - 1) carry += incl;
+        if (lane == 63) waveSum[wave] = inc;
         __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < SLAB_BLOCK / 64; ++w) { const uint32_t c = waveSum[w]; if (w < wave) before += c; all += c; }
+        if (i < nBlocks) row[i] = carry + before + inc - v;
+        carry += all;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
@@ -107,6 +105,7 @@ template <typename R> struct SlabOut {
     uint32_t *hash, *index;  // radix-sort keys/values of the next step for the compacted particles (saves a hash pass)
     const uint32_t *prevHash; // sorted keys of the step that produced `pos` (slot order), or null
     uint32_t *prevPacked;     // their compacted copy for the coherent re-sort (nrs_kernels_resort.h), or null
+    uint32_t *tileMovers;     // with prevPacked: per 256-slot tile of the COMPACTED array, slots whose key changed
     T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
     unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
     uint32_t cap;            // particles per message buffer
@@ -153,9 +152,14 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
                 case ST_STAY: {
                     out.stayPos[idx] = p; out.stayVel[idx] = v;
                     const I3 g = calcGridPos<R>(P, xyz<R>(p));
-                    out.hash[idx] = calcGridHash<R>(P, g.x, g.y, g.z);
+                    const uint32_t key = calcGridHash<R>(P, g.x, g.y, g.z);
+                    out.hash[idx] = key;
                     out.index[idx] = idx;
-                    if (out.prevPacked) out.prevPacked[idx] = out.prevHash ? out.prevHash[i] : 0xffffffffu;
+                    if (out.prevPacked) {
+                        const uint32_t prev = out.prevHash ? out.prevHash[i] : 0xffffffffu;
+                        out.prevPacked[idx] = prev;
+                        if (prev != key) atomicAdd(&out.tileMovers[idx / SLAB_BLOCK], 1u);
+                    }
                     break;
                 }
                 case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
@@ -222,7 +226,7 @@ template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
                                                            typename Vec4T<R>::type *__restrict__ dstVel, uint32_t *__restrict__ hash,
                                                            uint32_t *__restrict__ index, uint32_t *__restrict__ prevPacked,
-                                                           uint32_t dstBase)
+                                                           uint32_t *__restrict__ tileMovers, uint32_t dstBase)
 {
     const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (i >= A.start[5]) return;
@@ -235,7 +239,10 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendP
     const I3 g = calcGridPos<R>(P, xyz<R>(p));
     hash[dstBase + i] = calcGridHash<R>(P, g.x, g.y, g.z);
     index[dstBase + i] = dstBase + i;
-    if (prevPacked) prevPacked[dstBase + i] = 0xffffffffu; // new to this rank's arrays: never a "stayer"
+    if (prevPacked) { // new to this rank's arrays: never a "stayer" of the coherent re-sort
+        prevPacked[dstBase + i] = 0xffffffffu;
+        atomicAdd(&tileMovers[(dstBase + i) / SLAB_BLOCK], 1u);
+    }
 }
 
 } // namespace nrs
