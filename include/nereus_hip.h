@@ -86,6 +86,7 @@ enum {
     NRS_E_CAPACITY = -3, /* more particles than nrs_config.capacity */
     NRS_E_STATE = -4,    /* call not valid in the context's current state */
     NRS_E_NODEVICE = -5, /* no usable HIP device */
+    NRS_E_NOTREADY = -6, /* non-blocking query: the result is not there yet */
 };
 
 typedef struct nrs_config {
@@ -194,6 +195,18 @@ int nrs_synchronize(nrs_ctx *ctx);
 /* D2H: replaces the cudaMemcpy D2H at the end of update() (sph.cpp:283-284, iisph.cpp:214-216).
  * Any pointer may be NULL.  Order = grid-hash order of the last step, as in the reference. */
 int nrs_download(nrs_ctx *ctx, void *pos4, void *vel4, void *pres);
+/* Viewer hand-off that does not stall the simulation (consumer: the render loop's getHostPos(), main.cpp:587-588;
+ * the reference copies pos+vel back synchronously at the end of every update(), sph.cpp:283-284).
+ * nrs_snapshot_begin copies the current positions (and velocities if with_vel != 0) device-to-device into a staging
+ * buffer on the context's stream, then to page-locked host memory owned by the library on a separate copy stream:
+ * steps enqueued afterwards overlap with the PCIe transfer.  Two snapshots can be in flight (a third call first waits
+ * for the oldest).  nrs_snapshot_wait hands out the OLDEST pending snapshot: with block == 0 it returns
+ * NRS_E_NOTREADY (not an error, nrs_last_error is not set) while the transfer is running.  The pointers stay valid
+ * until two further nrs_snapshot_begin calls; *step = number of nrs_step steps the state had seen.  vel4 is NULL for
+ * a snapshot taken without velocities. */
+int nrs_snapshot_begin(nrs_ctx *ctx, int with_vel);
+int nrs_snapshot_wait(nrs_ctx *ctx, int block, const void **pos4, const void **vel4, uint64_t *n, uint64_t *step);
+
 /* Copy one of NRS_ARR_* to host memory (dst_bytes must be >= the array's size; returns it in *out_bytes
  * when dst == NULL). */
 int nrs_get_array(nrs_ctx *ctx, int which, void *dst, uint64_t dst_bytes, uint64_t *out_bytes);

@@ -20,6 +20,7 @@ FLAG_REFERENCE_ORDER = 1
 FLAG_NO_FUSION = 4
 FLAG_NO_SHARED_LISTS = 8
 FLAG_FULL_SORT = 16
+E_NOTREADY = -6
 
 # NRS_STAGE_*
 STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
@@ -46,7 +47,7 @@ EXPORTS = [
     "nrs_step", "nrs_step_partial", "nrs_synchronize", "nrs_download", "nrs_get_array", "nrs_device_ptr",
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
-    "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats",
+    "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats", "nrs_snapshot_begin", "nrs_snapshot_wait",
 ]
 
 
@@ -110,6 +111,8 @@ def load_library(path=None):
     lib.nrs_slab_message_bytes.restype = u64
     lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.nrs_resort_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.nrs_snapshot_begin.argtypes = [vp, i32]
+    lib.nrs_snapshot_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     _lib = lib
     return lib
 
@@ -270,6 +273,27 @@ class Solver:
         out = (C.c_uint32 * int(ncells))()
         self._chk(self.lib.nrs_slab_histogram(self.h, int(first_cell), int(ncells), out))
         return np.frombuffer(out, dtype=np.uint32).copy()
+
+    def snapshot_begin(self, with_vel=False):
+        """start an asynchronous copy of the current positions (and velocities) to pinned host memory"""
+        self._chk(self.lib.nrs_snapshot_begin(self.h, 1 if with_vel else 0))
+
+    def snapshot_wait(self, block=True):
+        """oldest pending snapshot as (pos, vel or None, step) — numpy views of the library's pinned buffers, valid until
+        two more snapshot_begin calls — or None if block is False and the transfer is still running"""
+        pp, pv, n, step = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        rc = self.lib.nrs_snapshot_wait(self.h, 1 if block else 0, C.byref(pp), C.byref(pv), C.byref(n), C.byref(step))
+        if rc == E_NOTREADY:
+            return None
+        self._chk(rc)
+        ct = C.c_double if self.real == np.float64 else C.c_float
+
+        def view(ptr):
+            if not ptr.value or not n.value:
+                return np.empty((0, 4), self.real) if ptr.value or not n.value else None
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(int(n.value), 4))
+
+        return view(pp), (view(pv) if pv.value else None), int(step.value)
 
     def resort_stats(self):
         """(steps that used the coherent re-sort path, how many of them fell back to the full radix sort)"""

@@ -118,6 +118,8 @@ struct CtxBase {
     virtual int step(int nsteps, int stop) = 0;
     virtual int sync() = 0;
     virtual int download(void *pos4, void *vel4, void *pres) = 0;
+    virtual int snapshot_begin(int withVel) = 0;
+    virtual int snapshot_wait(int block, const void **pos4, const void **vel4, uint64_t *n, uint64_t *step) = 0;
     virtual int array(int which, void **dptr, uint64_t *bytes) = 0;
     virtual int stage_ms(int stage, float *ms, uint32_t *launches) = 0;
     virtual int reduce_max(int which, double *out) = 0;
@@ -215,6 +217,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         for (DevBuf *b : all) b->release();
         if (rsEvent) (void)hipEventDestroy(rsEvent);
         if (rsHostTotal) (void)hipHostFree(rsHostTotal);
+        snapshot_release();
         if (ownStream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -930,6 +933,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 cellsClean = true;
             }
             // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
+            ++stepsDone;
             slotOrderValid = fusedThisStep; // A holds the new state in the slot order of hashCur
             if (!fusedThisStep) { // the fused kernel already wrote the new state into A
                 std::swap(posA.p, posB.p);
@@ -946,6 +950,90 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         HIPCHK(hipStreamSynchronize(stream));
         return NRS_OK;
     }
+    // ---- asynchronous snapshots for a viewer (include/nereus_hip.h: nrs_snapshot_*) ---------------------------
+    struct Snap {
+        DevBuf dPos, dVel;
+        void *hPos = nullptr, *hVel = nullptr;
+        size_t hBytes = 0;
+        hipEvent_t staged = nullptr, done = nullptr;
+        uint64_t n = 0, step = 0;
+        bool withVel = false, pending = false;
+    };
+    Snap snaps[2];
+    int snapHead = 0, snapTail = 0; // next slot to fill / oldest pending slot
+    hipStream_t copyStream = nullptr;
+    uint64_t stepsDone = 0;
+    void snapshot_release()
+    {
+        for (Snap &sn : snaps) {
+            if (sn.pending && sn.done) (void)hipEventSynchronize(sn.done);
+            sn.dPos.release(); sn.dVel.release();
+            if (sn.hPos) (void)hipHostFree(sn.hPos);
+            if (sn.hVel) (void)hipHostFree(sn.hVel);
+            if (sn.staged) (void)hipEventDestroy(sn.staged);
+            if (sn.done) (void)hipEventDestroy(sn.done);
+            sn = Snap();
+        }
+        if (copyStream) (void)hipStreamDestroy(copyStream);
+        copyStream = nullptr;
+    }
+    int snapshot_begin(int withVel) override
+    {
+        if (midStep) return fail(NRS_E_STATE, "state is mid-update");
+        if (!copyStream) HIPCHK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+        Snap &sn = snaps[snapHead];
+        if (sn.pending) { // both slots in flight: the oldest is this one
+            HIPCHK(hipEventSynchronize(sn.done));
+            sn.pending = false;
+            snapTail = (snapHead + 1) % 2;
+        }
+        const size_t bytes = sizeof(T4) * (size_t)cap;
+        if (!sn.staged) {
+            HIPCHK(hipEventCreateWithFlags(&sn.staged, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sn.done, hipEventDisableTiming));
+        }
+        NRSCHK(sn.dPos.alloc(bytes));
+        if (!sn.hPos) HIPCHK(hipHostMalloc(&sn.hPos, bytes, hipHostMallocDefault));
+        if (withVel) {
+            NRSCHK(sn.dVel.alloc(bytes));
+            if (!sn.hVel) HIPCHK(hipHostMalloc(&sn.hVel, bytes, hipHostMallocDefault));
+        }
+        const size_t live = sizeof(T4) * (size_t)n;
+        if (live) {
+            HIPCHK(hipMemcpyAsync(sn.dPos.p, posA.p, live, hipMemcpyDeviceToDevice, stream));
+            if (withVel) HIPCHK(hipMemcpyAsync(sn.dVel.p, velA.p, live, hipMemcpyDeviceToDevice, stream));
+        }
+        HIPCHK(hipEventRecord(sn.staged, stream));
+        HIPCHK(hipStreamWaitEvent(copyStream, sn.staged, 0));
+        if (live) {
+            HIPCHK(hipMemcpyAsync(sn.hPos, sn.dPos.p, live, hipMemcpyDeviceToHost, copyStream));
+            if (withVel) HIPCHK(hipMemcpyAsync(sn.hVel, sn.dVel.p, live, hipMemcpyDeviceToHost, copyStream));
+        }
+        HIPCHK(hipEventRecord(sn.done, copyStream));
+        sn.n = n; sn.step = stepsDone; sn.withVel = withVel != 0; sn.pending = true;
+        snapHead = (snapHead + 1) % 2;
+        return NRS_OK;
+    }
+    int snapshot_wait(int block, const void **pos4, const void **vel4, uint64_t *np, uint64_t *step) override
+    {
+        Snap &sn = snaps[snapTail];
+        if (!sn.pending) return fail(NRS_E_STATE, "no snapshot in flight (nrs_snapshot_begin first)");
+        if (block) {
+            HIPCHK(hipEventSynchronize(sn.done));
+        } else {
+            const hipError_t e = hipEventQuery(sn.done);
+            if (e == hipErrorNotReady) return NRS_E_NOTREADY;
+            HIPCHK(e);
+        }
+        sn.pending = false;
+        snapTail = (snapTail + 1) % 2;
+        if (pos4) *pos4 = sn.hPos;
+        if (vel4) *vel4 = sn.withVel ? sn.hVel : nullptr;
+        if (np) *np = sn.n;
+        if (step) *step = sn.step;
+        return NRS_OK;
+    }
+
     int download(void *pos4, void *vel4, void *pres) override
     {
         if (pos4) HIPCHK(hipMemcpyAsync(pos4, posA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
@@ -1113,6 +1201,16 @@ int nrs_synchronize(nrs_ctx *ctx)
 {
     CTX_GUARD(ctx);
     return ctx->impl->sync();
+}
+int nrs_snapshot_begin(nrs_ctx *ctx, int with_vel)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->snapshot_begin(with_vel);
+}
+int nrs_snapshot_wait(nrs_ctx *ctx, int block, const void **pos4, const void **vel4, uint64_t *n, uint64_t *step)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->snapshot_wait(block, pos4, vel4, n, step);
 }
 int nrs_download(nrs_ctx *ctx, void *pos4, void *vel4, void *pres)
 {

@@ -79,7 +79,8 @@ SPH::SPH()
     : m_gridSortBits(32), m_pos(nullptr), m_vel(nullptr), m_density(nullptr), m_pressure(nullptr), m_forces(nullptr),
       m_colors(nullptr), m_numParticles(0), m_hostCapacity(0), m_bi(nullptr), m_vbi(nullptr), m_num_boundaries(0),
       m_ctx(nullptr), m_ctxCapacity(0), m_hostDirty(true), m_deviceNewer(false), m_boundariesPending(false),
-      m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f)
+      m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f), m_asyncReadback(false),
+      m_framesInFlight(0), m_frame(nullptr), m_frameCount(0), m_frameStep(0), m_frameIsCurrent(false)
 {
     std::cout << GREEN << "construction of sph based system" << RESET << std::endl;
     std::memset(&m_params, 0, sizeof(m_params));
@@ -108,7 +109,8 @@ SPH::SPH(SphSimParams params)
     : m_params(params), m_gridSortBits(32), m_pos(nullptr), m_vel(nullptr), m_density(nullptr), m_pressure(nullptr),
       m_forces(nullptr), m_colors(nullptr), m_numParticles(0), m_hostCapacity(0), m_bi(nullptr), m_vbi(nullptr),
       m_num_boundaries(0), m_ctx(nullptr), m_ctxCapacity(0), m_hostDirty(true), m_deviceNewer(false),
-      m_boundariesPending(false), m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f)
+      m_boundariesPending(false), m_eagerSync(false), m_initialized(false), m_cfl(false), m_cflLambda(0.4f), m_asyncReadback(false),
+      m_framesInFlight(0), m_frame(nullptr), m_frameCount(0), m_frameStep(0), m_frameIsCurrent(false)
 {
     kernelFactors(m_params, 2);
     _initialize();
@@ -175,9 +177,12 @@ void SPH::reserveParticles(SUint capacity)
 void SPH::releaseContext()
 {
     if (m_ctx) {
-        nrs_destroy(m_ctx);
+        nrs_destroy(m_ctx); // also frees the pinned frames
         m_ctx = nullptr;
         m_ctxCapacity = 0;
+        m_framesInFlight = 0;
+        m_frame = nullptr;
+        m_frameIsCurrent = false;
         if (m_num_boundaries) m_boundariesPending = true;
     }
 }
@@ -251,13 +256,64 @@ void SPH::update()
     if (nrs_set_params(m_ctx, &m_params) != NRS_OK) fatal("nrs_set_params"); // setParameters, every step
     if (nrs_step(m_ctx, 1) != NRS_OK) fatal("nrs_step");
     m_deviceNewer = true;
+    m_frameIsCurrent = false;
+    if (m_asyncReadback) {
+        if (m_framesInFlight == 2) collectFrames(false); // the library would wait for the oldest anyway: keep it
+        if (nrs_snapshot_begin(m_ctx, 0) != NRS_OK) fatal("nrs_snapshot_begin");
+        ++m_framesInFlight;
+    }
     if (m_eagerSync) pullDeviceToHost();
+}
+
+void SPH::setAsyncReadback(bool on)
+{
+    if (!on && m_ctx) collectFrames(true);
+    m_asyncReadback = on;
+}
+
+// take every finished snapshot out of the library (all of them, blocking, if waitForAll; else at least the oldest when
+// two are in flight or none has ever arrived)
+void SPH::collectFrames(bool waitForAll) const
+{
+    while (m_framesInFlight > 0) {
+        const bool mustWait = waitForAll || m_framesInFlight == 2 || m_frame == nullptr;
+        const void *p = nullptr;
+        uint64_t n = 0, step = 0;
+        const int rc = nrs_snapshot_wait(m_ctx, mustWait ? 1 : 0, &p, nullptr, &n, &step);
+        if (rc == NRS_E_NOTREADY) break;
+        if (rc != NRS_OK) fatal("nrs_snapshot_wait");
+        --m_framesInFlight;
+        m_frame = (const SReal *)p;
+        m_frameCount = (SUint)n;
+        m_frameStep = step;
+        m_frameIsCurrent = (m_framesInFlight == 0); // the newest begun snapshot was taken right after the last update()
+    }
+}
+
+const SReal *SPH::latestFrame(SUint *numParticles, unsigned long long *step)
+{
+    if (!m_asyncReadback || !m_ctx) { // no snapshots: the synchronous path
+        pullDeviceToHost();
+        if (numParticles) *numParticles = m_numParticles;
+        if (step) *step = 0;
+        return m_pos;
+    }
+    collectFrames(false);
+    if (numParticles) *numParticles = m_frameCount;
+    if (step) *step = m_frameStep;
+    return m_frame;
 }
 
 SReal *&SPH::getPos() { pullDeviceToHost(); m_hostDirty = true; return m_pos; }
 SReal *&SPH::getVel() { pullDeviceToHost(); m_hostDirty = true; return m_vel; }
 SReal *&SPH::getCol() { return m_colors; }
-SReal *SPH::getHostPos() const { pullDeviceToHost(); return m_pos; }
+SReal *SPH::getHostPos() const
+{
+    if (m_asyncReadback && m_ctx && m_deviceNewer && m_framesInFlight > 0) collectFrames(true);
+    if (m_asyncReadback && m_frameIsCurrent && m_deviceNewer && m_frame) return const_cast<SReal *>(m_frame);
+    pullDeviceToHost();
+    return m_pos;
+}
 SReal *SPH::getHostVel() const { pullDeviceToHost(); return m_vel; }
 SReal *SPH::getHostPressure() const { pullDeviceToHost(); return m_pressure; }
 SReal *SPH::getHostCol() const { return m_colors; }

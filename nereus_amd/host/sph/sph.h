@@ -101,6 +101,14 @@ public:
     // the reference has none.  A restored solver continues bit-identically.
     bool saveState(const char *path) const;
     bool loadState(const char *path);
+    // Viewer hand-off that does not stall the solver (the reference copies pos+vel back synchronously at the end of every
+    // update(), sph.cpp:283-284, and main.cpp:587-588 uploads them to a VBO).  With asynchronous read-back on, update()
+    // also starts a device -> page-locked-host copy of the new positions on a copy stream (nrs_snapshot_begin), which
+    // overlaps with the updates enqueued after it.  latestFrame() never waits for the solver: it returns the newest
+    // frame whose transfer has completed (at most two updates old; it blocks only while no frame has arrived yet);
+    // getHostPos() keeps the reference's meaning (positions after the last update()) and waits for that frame.
+    void setAsyncReadback(bool on);
+    const SReal *latestFrame(SUint *numParticles = nullptr, unsigned long long *step = nullptr);
 
 protected:
     virtual int solverKind() const; // NRS_SOLVER_*
@@ -132,6 +140,13 @@ protected:
     bool m_initialized;
     bool m_cfl;
     SReal m_cflLambda;
+    bool m_asyncReadback;
+    mutable int m_framesInFlight;        // snapshots begun and not yet collected (0..2)
+    mutable const SReal *m_frame;        // newest collected frame (library-owned pinned memory)
+    mutable SUint m_frameCount;
+    mutable unsigned long long m_frameStep;
+    mutable bool m_frameIsCurrent;       // m_frame shows the state after the last update()
+    void collectFrames(bool waitForAll) const;
 };
 
 NEREUS_NAMESPACE_END

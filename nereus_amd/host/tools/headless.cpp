@@ -52,7 +52,7 @@ int main(int argc, char **argv)
     unsigned iters = 0;
     if (mode == "params") {
         dump(argv[3], sim, 0, bi, vbi);
-    } else if (mode == "run") {
+    } else if (mode == "run" || mode == "frames") {
         if (argc < 6) die("run needs <in.bin> <steps> <out.bin>");
         FILE *f = std::fopen(argv[3], "rb");
         if (!f) die("cannot open input");
@@ -71,7 +71,21 @@ int main(int argc, char **argv)
             sim->updateGpuBoundaries(nb);
         }
         const int steps = std::atoi(argv[4]);
-        for (int s = 0; s < steps; ++s) sim->update();
+        if (mode == "frames") { // render-loop pattern: update(); draw(latestFrame()) — the frame may lag, never the solver
+            sim->setAsyncReadback(true);
+            unsigned long long last = 0;
+            for (int s = 0; s < steps; ++s) {
+                sim->update();
+                SUint fn = 0;
+                unsigned long long fstep = 0;
+                const SReal *frame = sim->latestFrame(&fn, &fstep);
+                if (!frame || fn != sim->getNumParticles()) die("latestFrame: no frame");
+                if (fstep < last || fstep > (unsigned long long)(s + 1) || fstep + 2 < (unsigned long long)(s + 1)) die("latestFrame: stale or out of order");
+                last = fstep;
+            }
+        } else {
+            for (int s = 0; s < steps; ++s) sim->update();
+        }
         if (iisph) iters = static_cast<Nereus::IISPH *>(sim)->getLastIterations();
         dump(argv[5], sim, iters, bi, vbi);
     } else if (mode == "resume" || mode == "cfl") {

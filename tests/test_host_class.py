@@ -123,6 +123,58 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, hip_lib, kind, solver):
 
 
 @pytest.mark.gpu
+def test_async_readback_frames(tmp_path, hip_lib):
+    """setAsyncReadback: latestFrame() hands out pinned frames that lag at most two updates (checked by the driver),
+    and getHostPos() after the loop is the state of a plain run, bit for bit."""
+    p, sc = small_dam_break()
+    fin = str(tmp_path / "in.bin")
+    _write_in(fin, sc["pos"], sc["vel"], sc["bi"], sc["vbi"])
+    plain, framed = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    subprocess.check_call([_driver(), "run", "sesph", fin, "9", plain], stdout=subprocess.DEVNULL)
+    subprocess.check_call([_driver(), "frames", "sesph", fin, "9", framed], stdout=subprocess.DEVNULL)
+    a, b = _read_out(plain), _read_out(framed)
+    np.testing.assert_array_equal(a["pos"], b["pos"])
+    np.testing.assert_array_equal(a["vel"], b["vel"])
+
+
+@pytest.mark.gpu
+def test_snapshot_api(hip_lib):
+    """nrs_snapshot_begin / nrs_snapshot_wait: the snapshot is the state at the time of the call even though more steps
+    were enqueued behind it; two in flight; non-blocking poll."""
+    from nereus_amd import capi
+
+    p, sc = small_dam_break((20, 16, 14))
+    s = capi.Solver(p, len(sc["pos"]))
+    s.set_particles(sc["pos"], sc["vel"])
+    s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    s.step(3)
+    want3 = s.download()
+    s.snapshot_begin(with_vel=True)
+    s.step(2)
+    s.snapshot_begin()
+    s.step(4)
+    pos, vel, step = s.snapshot_wait()
+    assert step == 3
+    np.testing.assert_array_equal(pos, want3[0])
+    np.testing.assert_array_equal(vel, want3[1])
+    got = None
+    for _ in range(100000):
+        got = s.snapshot_wait(block=False)
+        if got is not None:
+            break
+    assert got is not None and got[2] == 5 and got[1] is None
+    ref = capi.Solver(p, len(sc["pos"]))
+    ref.set_particles(sc["pos"], sc["vel"])
+    ref.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    ref.step(5)
+    np.testing.assert_array_equal(got[0], ref.download()[0])
+    with pytest.raises(capi.NereusError):
+        s.snapshot_wait()
+    s.close()
+    ref.close()
+
+
+@pytest.mark.gpu
 def test_adaptive_cfl_timestep(tmp_path, hip_lib):
     """setAdaptiveTimestep: dt = 0.4 * h / max|v| before every step (the reference's disabled CFL block)."""
     p, sc = small_dam_break()
