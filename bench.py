@@ -39,8 +39,8 @@ IISPH_STAGE_BYTES_F32 = {"i_density": 20, "i_displacement": 100, "i_advection": 
 # a full step on the production kernels runs forces + integrate + next-step hash as ONE launch: its algorithmic
 # bytes are the sum of the three reference stages it implements
 FUSED_FORCES_BYTES_F32 = STAGE_BYTES_F32["forces"] + STAGE_BYTES_F32["integrate"] + STAGE_BYTES_F32["hash"]
-KERNEL_OF_STAGE = {"forces": "k_forces_lists", "density": "k_density_tiled", "reorder": "k_reorder", "hash": "k_hash",
-                   "integrate": "k_integrate", "sort": "radix_sort_onesweep"}
+KERNEL_OF_STAGE = {"forces": "k_forces_lists", "density": "k_density_tiled", "reorder": "k_reorder_merged", "hash": "k_hash",
+                   "integrate": "k_integrate", "sort": "k_resort_split"}
 
 
 def per_stage_roofline(warm, n, num_cells, production):
@@ -66,7 +66,7 @@ def per_stage_roofline(warm, n, num_cells, production):
 def measured_traffic(stage, n):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC profile (2*FETCH_SIZE + WRITE_SIZE,
     the gfx950 correction of MI355X_MICROARCH.md), scaled by particle count; None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_c_ns10M_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_ns10M_hbm_traffic.json")
     try:
         doc = json.load(open(path))
         k = doc["kernels"][KERNEL_OF_STAGE[stage]]
@@ -273,7 +273,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(dominant, n),
-            "traffic_source": "profiles/r01_c_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
+            "traffic_source": "profiles/r01_e_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
                               "scaled by particle count",
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,

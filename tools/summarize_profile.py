@@ -1,0 +1,60 @@
+"""Turn the raw output of tools/profile_bench.sh (gpurun_out/prof_<tag>/) into the committed summaries:
+profiles/<name>_kernel_stats.csv (copy of rocprofv3's --stats table) and profiles/<name>_hbm_traffic.json
+(HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE passes, raw and with the gfx950 correction of
+MI355X_MICROARCH.md: 2*FETCH_SIZE + WRITE_SIZE; counter values are KB per dispatch).
+usage: python tools/summarize_profile.py gpurun_out/prof_r01e r01_e_ns10M "workload text" particles"""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+SHORT = [("k_density_tiled", "k_density_tiled"), ("k_forces_lists", "k_forces_lists"), ("k_forces_tiled", "k_forces_tiled"),
+         ("k_reorder_merged", "k_reorder_merged"), ("k_reorder_boundary", "k_reorder_boundary"), ("k_reorder", "k_reorder"),
+         ("k_clear_cells", "k_clear_cells"), ("k_hash", "k_hash"), ("k_resort_split", "k_resort_split"),
+         ("k_resort_scan_tiles", "k_resort_scan_tiles"), ("k_resort_count", "k_resort_count"), ("k_integrate", "k_integrate"),
+         ("onesweep_histograms", "radix_sort_histograms"), ("onesweep_scan", "radix_sort_scan_histograms"),
+         ("radix_sort_onesweep", "radix_sort_onesweep"), ("merge", "rocprim_merge"), ("fillBuffer", "fillBuffer"),
+         ("copyBuffer", "copyBuffer")]
+
+
+def short(name):
+    for key, s in SHORT:
+        if key in name:
+            return s
+    return name[:60]
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    src, name, workload, particles = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(root, name + "_kernel_stats.csv"))
+    f = per_kernel(os.path.join(src, "fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+    w = per_kernel(os.path.join(src, "write", "w_counter_collection.csv"), "WRITE_SIZE")
+    out = {"workload": workload,
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter values are KB per dispatch; "
+                   "corrected = 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
+                   "(uncalibrated for gather access patterns)",
+           "particles": particles, "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, [0.0]), w.get(k, [0.0])
+        fa, wa = sum(fk) / len(fk), sum(wk) / len(wk)
+        out["kernels"][k] = {"FETCH_SIZE_KB_avg": fa, "FETCH_SIZE_dispatches": len(fk), "WRITE_SIZE_KB_avg": wa,
+                             "WRITE_SIZE_dispatches": len(wk), "hbm_bytes_per_launch_corrected": 1024.0 * (2 * fa + wa),
+                             "hbm_bytes_per_launch_raw": 1024.0 * (fa + wa)}
+    json.dump(out, open(os.path.join(root, name + "_hbm_traffic.json"), "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print("%-28s %4d launches  %8.1f MB/launch (corrected)" % (k, v["FETCH_SIZE_dispatches"], v["hbm_bytes_per_launch_corrected"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
