@@ -40,6 +40,11 @@ constexpr int HIT_TAG_SHIFT = 27;
 //   r2LeH2  : smallest float T with  fl(sqrtf(T)^2) > h*h    ⇒  !(length(r)^2 > h^2)     ⇔ d2 < T
 struct CutThresholds { float lenLtIr, r2LeH2; };
 
+// waves per SIMD the fp32 list-driven force kernel is compiled for: 7 caps it at 72 VGPRs (3 dwords spilled with
+// boundaries) and measured 0.487 -> 0.465 ms at 10 M particles; 8 (64 VGPRs) spills into the hit loop: 0.563 ms
+#ifndef FORCES_LISTS_MIN_WAVES
+#define FORCES_LISTS_MIN_WAVES 7
+#endif
 constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (8 costs 16 VGPRs, slower)
 
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R>
 // scan-free form: consumes the hit lists the density kernel of the same step published (no LDS ⇒ occupancy is
 // bounded by registers only)
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
-__global__ __launch_bounds__(BLOCK) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? FORCES_LISTS_MIN_WAVES : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const typename Vec4T<R>::type *__restrict__ sVel,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,
