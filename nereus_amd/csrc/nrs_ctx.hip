@@ -315,7 +315,12 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         Params<R> q;
         std::memcpy(&q, params, sizeof(q));
         const bool regrid = q.numCells != P.numCells;
-        if (std::memcmp(&P, &q, sizeof(P)) != 0) { hashReady = false; slotOrderValid = false; } // grid/origin may have changed: re-hash
+        // the keys the fused force kernel left for the next step depend on the grid only (a new time step or viscosity
+        // does not invalidate them: the reference calls setParameters every update(), the CFL variant with a new dt)
+        const bool sameGrid = std::memcmp(P.gridSize, q.gridSize, sizeof(P.gridSize)) == 0 && q.numCells == P.numCells &&
+                              std::memcmp(P.worldOrigin, q.worldOrigin, sizeof(P.worldOrigin)) == 0 &&
+                              std::memcmp(P.cellSize, q.cellSize, sizeof(P.cellSize)) == 0;
+        if (!sameGrid) { hashReady = false; slotOrderValid = false; }
         P = q;
         if (regrid) {
             NRSCHK(alloc_cells());

@@ -208,21 +208,22 @@ def test_kernel_path_flags_are_bitwise_equivalent(hip_lib):
             np.testing.assert_array_equal(a, b)
 
 
-def test_coherent_resort_equals_full_sort(hip_lib):
+@pytest.mark.parametrize("double", [False, True], ids=["f32", "f64"])
+def test_coherent_resort_equals_full_sort(hip_lib, double):
     """Default path (sort only the particles that changed cell, merge into the rest) vs NRS_FLAG_FULL_SORT (the
     reference's sort-everything): identical hash / index / cell tables / state after every checked step, the oracle's
     hash and index bit for bit, and the fall-back when most particles change cell."""
-    p, sc = small_dam_break((40, 36, 32))
+    p, sc = small_dam_break((40, 36, 32), double=double)
     n = len(sc["pos"])
     assert n >= 32768  # below that the context always sorts from scratch
     names = ("hash", "index", "cellStart", "cellEnd", "dens")
     solvers = []
     for flags in (0, capi.FLAG_FULL_SORT):
-        s = capi.Solver(p, n, flags=flags)
+        s = capi.Solver(p, n, flags=flags, double=double)
         s.set_particles(sc["pos"], sc["vel"])
         s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
         solvers.append(s)
-    o = Oracle(p, solver=SESPH, threads=min(16, os.cpu_count() or 1))
+    o = Oracle(p, double=double, solver=SESPH, threads=min(16, os.cpu_count() or 1))
     o.set_particles(sc["pos"], sc["vel"])
     o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     done = 0
@@ -246,7 +247,7 @@ def test_coherent_resort_equals_full_sort(hip_lib):
     rng = np.random.default_rng(5)
     pos = solvers[0].download()[0]
     vel = np.zeros_like(pos)
-    vel[:, :3] = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32) * (0.9 * h / dt)
+    vel[:, :3] = rng.uniform(-1.0, 1.0, (n, 3)).astype(pos.dtype) * (0.9 * h / dt)
     for s in solvers:
         s.set_particles(pos, vel)
         s.step(3)
