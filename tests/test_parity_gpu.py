@@ -445,6 +445,29 @@ def test_full_size_c2_properties(hip_lib):
     assert rel_err(a["forces"], o.get("forces")) <= TOL_STAGE
 
 
+def test_full_size_c2_resort_long_run_bitwise(hip_lib):
+    """BASELINE config C2 for 150 steps: the default path (coherent re-sort, fused launches, shared hit lists) and the
+    reference-shaped path (full sort every step, separate launches) end in the same bits; the mover fraction grows
+    along the run, every step after the first took the merge path."""
+    p = Oracle.default_params(SESPH)
+    sc = scene.dam_break("C2", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    n = len(sc["pos"])
+    outs = []
+    for flags in (0, capi.FLAG_FULL_SORT | capi.FLAG_NO_FUSION):
+        s = capi.Solver(p, n, flags=flags)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step(150)
+        outs.append(s.download() + (s.get("hash"), s.get("index"), s.get("dens")))
+        if flags == 0:
+            assert s.resort_stats() == (149, 0)
+        s.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    h = outs[0][2].astype(np.int64)
+    assert np.all(np.diff(h) >= 0) and np.array_equal(np.sort(outs[0][3]), np.arange(n, dtype=np.uint32))
+
+
 def test_full_size_c3_iisph_properties(hip_lib):
     """BASELINE config C3 (160^3 = 4,096,000 particles, IISPH, fp32): one full step against the oracle on the same
     inputs (threads on the host cores), plus solver-loop properties."""
