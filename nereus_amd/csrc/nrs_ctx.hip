@@ -727,12 +727,16 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                                    presB.as<R>(), N);
             std::swap(I.P_l, I.P_l_next);
             std::swap(P_l.p, P_l2.p);
-            double acc = 0.0;
-            NRSCHK(reduce_sum(densCorr.as<R>(), N, &acc));
-            rho_avg = (R)acc;
-            rho_avg /= N;
             l++;
             if (maxIters && l >= maxIters) break;
+            // the loop condition reads rho_avg only once l >= 2 (sph_cuda.cu:736: `|| l < 2`): the average of the first
+            // iteration is never looked at, so its reduction and host round trip are skipped
+            if (l >= 2) {
+                double acc = 0.0;
+                NRSCHK(reduce_sum(densCorr.as<R>(), N, &acc));
+                rho_avg = (R)acc;
+                rho_avg /= N;
+            }
         }
         lastIters = l;
         NRSCHK(ev_end());

@@ -15,6 +15,19 @@
 #pragma once
 #include "nrs_kernels_tiled.h"
 
+// waves per SIMD the fp32 list kernels are compiled for (measured at config C3, 4.1 M particles): displacement
+// unbounded (92 VGPRs, 5 waves) 0.389 ms, 6 waves 0.366, 7 waves 0.351; advection 7 -> 8 waves 0.239 -> 0.234;
+// pressure (2 iterations incl. the rest of the solve) unbounded 1.093, 5 waves 1.055, 6 waves 1.178 (spills)
+#ifndef IISPH_DISP_WAVES
+#define IISPH_DISP_WAVES 7
+#endif
+#ifndef IISPH_ADV_WAVES
+#define IISPH_ADV_WAVES 8
+#endif
+#ifndef IISPH_PRES_WAVES
+#define IISPH_PRES_WAVES 5
+#endif
+
 namespace nrs {
 
 // Walk the merged hit lists; f(j, isBoundary, newPartial) with newPartial = first hit of a (cell, kind) group.
@@ -32,7 +45,7 @@ template <typename F> NRS_DEV void for_each_hit(const uint32_t *lbase, uint32_t 
 
 // ---- computeDisplacementFactor (sph_kernel_impl.cuh:851-963) -----------------------------------------------
 template <typename R, int KSET, bool SURF, bool HAS_B>
-__global__ __launch_bounds__(BLOCK) void k_displacement_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) void k_displacement_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
                                                               const typename Vec4T<R>::type *__restrict__ sPos,
                                                               const typename Vec4T<R>::type *__restrict__ sVel,
                                                               const R *__restrict__ sDens, const R *__restrict__ sPres,
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_displacement_lists(Params<R> P, GridV
 
 // ---- computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) --------------------------------------------------
 template <typename R, int KSET, bool HAS_B>
-__global__ __launch_bounds__(BLOCK) void k_advection_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void k_advection_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
                                                            const typename Vec4T<R>::type *__restrict__ sPos,
                                                            const typename Vec4T<R>::type *__restrict__ sVel,
                                                            const R *__restrict__ sDens, const R *__restrict__ sPres,
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R>
 // ---- computePressure without boundary particles (sph_kernel_impl.cuh:1330-1492; Q5: skips j == inv[i], keeps self;
 //      Q7: reads P_l, writes P_l_next) ----------------------------------------------------------------------------
 template <typename R, int KSET, bool HAS_B>
-__global__ __launch_bounds__(BLOCK) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
                                                           const typename Vec4T<R>::type *__restrict__ sPos,
                                                           const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n)
 {
