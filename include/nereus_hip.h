@@ -253,8 +253,8 @@ int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32
 
 /* Coherent re-sort statistics since nrs_create: steps whose (hash, index) pairs were produced by sorting only the
  * particles that changed cell and merging them into the rest, and how many of those fell back to the full radix sort
- * because more than 1/8 of the particles had moved.  (Steps after an upload, partial steps, IISPH and slab runs always
- * use the full sort and are not counted.) */
+ * because more than 1/8 of the particles had moved.  (Steps after an upload or a grid change and partial steps
+ * always use the full sort and are not counted.) */
 int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */

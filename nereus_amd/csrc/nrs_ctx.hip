@@ -281,7 +281,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         HIPCHK(rocprim::radix_sort_pairs<SortCfg10>(nullptr, tmp10, k, vv, (size_t)cap, 0u, 30u, stream));
         size_t tmpAll = std::max(tmp, std::max(tmp9, tmp10));
         // coherent re-sort: SESPH steps on the production kernels re-use the previous step's order
-        if (!iisph() && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_FUSION | NRS_FLAG_FULL_SORT)) && cap >= RESORT_MIN_PARTICLES) {
+        if (!(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_FUSION | NRS_FLAG_FULL_SORT)) && cap >= RESORT_MIN_PARTICLES) {
             const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
             const size_t mcap = cap / RESORT_MAX_MOVER_DIV + 1;
             NRSCHK(rsMovers.alloc(8 * cap)); NRSCHK(rsMoversAlt.alloc(8 * mcap)); NRSCHK(rsStayers.alloc(8 * cap)); NRSCHK(rsMerged.alloc(8 * cap));
@@ -586,6 +586,24 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    // first half of the next step's sort, queued right behind the kernel that produced the keys in hashNext and counted
+    // the movers per tile: scan of the tile counts (total to the host) + stable split into movers / stayers
+    int queue_resort_split(uint32_t N)
+    {
+        NRSCHK(ev_begin(NRS_STAGE_SORT));
+        const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+        uint32_t *sc = rsScalars.as<uint32_t>();
+        hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
+                           rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
+                           (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
+        HIPCHK(hipEventRecord(rsEvent, stream));
+        hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, rsTileOffset.as<uint32_t>(),
+                           rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+        rsPending = true;
+        NRSCHK(ev_end());
+        return NRS_OK;
+    }
+
     template <bool HAS_B> int sesph_tail(int stop)
     {
         const uint32_t N = (uint32_t)n;
@@ -627,16 +645,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             fusedThisStep = true;
             if (resort) {
                 NRSCHK(ev_end());
-                NRSCHK(ev_begin(NRS_STAGE_SORT)); // first half of the next step's sort: scan of the tile counts + split
-                const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
-                uint32_t *sc = rsScalars.as<uint32_t>();
-                hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
-                                   rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
-                                   (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
-                HIPCHK(hipEventRecord(rsEvent, stream));
-                hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, rsTileOffset.as<uint32_t>(),
-                                   rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
-                rsPending = true;
+                NRSCHK(queue_resort_split(N));
             }
         } else {
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
@@ -749,8 +758,25 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_PFORCE) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_INTEGRATE));
-        hipLaunchKernelGGL((k_iisph_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), velAdv.as<T4>(), forcesP.as<T4>(), N);
+        // a full step on the production kernels also leaves the next step's sort keys (and the split of the coherent
+        // re-sort), as the fused SESPH force kernel does
+        const bool keys = !refOrder() && stop == 0 && !(cfg.flags & NRS_FLAG_NO_FUSION);
+        const bool resort = keys && rsMovers.p && (uint64_t)N >= RESORT_MIN_PARTICLES;
+        uint32_t *nh = nullptr, *ni = nullptr;
+        if (keys) {
+            nh = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+            ni = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+        }
+        if (resort) NRSCHK(clean_tile_counts());
+        hipLaunchKernelGGL((k_iisph_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), velAdv.as<T4>(), forcesP.as<T4>(), N,
+                           nh, ni, resort ? (const uint32_t *)hashCur : (const uint32_t *)nullptr,
+                           resort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr);
         NRSCHK(ev_end());
+        if (keys) {
+            hashNext = nh; indexNext = ni;
+            hashReady = true;
+            if (resort) NRSCHK(queue_resort_split(N));
+        }
         return NRS_OK;
     }
 

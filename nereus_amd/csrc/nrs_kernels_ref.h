@@ -680,8 +680,12 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename
                                                            typename Vec4T<R>::type *__restrict__ vel,
                                                            const typename Vec4T<R>::type *__restrict__ velAdv,
                                                            const typename Vec4T<R>::type *__restrict__ forcesP,
-                                                           uint32_t n)
+                                                           uint32_t n, uint32_t *__restrict__ nextHash,
+                                                           uint32_t *__restrict__ nextIndex, const uint32_t *__restrict__ prevHash,
+                                                           uint32_t *__restrict__ tileMovers)
 {
+    // nextHash/nextIndex (both or neither): also emit the next step's sort keys (calcHashD of the new position);
+    // prevHash/tileMovers (both or neither): count the slots whose key changes, for the coherent re-sort
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const R dt = P.timestep, pm = P.particleMass;
@@ -692,6 +696,13 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename
     const V3<R> newPos = pos1 + (dt * newVel);
     pos[i] = mk4<R>(newPos, (R)1.0);
     vel[i] = mk4<R>(newVel, (R)0.0);
+    if (nextHash) {
+        const I3 g = calcGridPos<R>(P, newPos);
+        const uint32_t h = calcGridHash<R>(P, g.x, g.y, g.z);
+        nextHash[i] = h;
+        nextIndex[i] = i;
+        if (tileMovers && h != prevHash[i]) atomicAdd(&tileMovers[i / BLOCK], 1u);
+    }
 }
 
 // deterministic two-pass sum of an SReal array in double (replaces thrust::reduce, sph_cuda.cu:816-819)

@@ -259,6 +259,28 @@ def test_coherent_resort_equals_full_sort(hip_lib, double):
         s.close()
 
 
+def test_iisph_coherent_resort_equals_full_sort(hip_lib):
+    """IISPH: the integrate kernel leaves the next step's keys and mover counts; default path vs hash + full sort."""
+    p, sc = small_dam_break((36, 34, 32), solver=IISPH)
+    n = len(sc["pos"])
+    assert n >= 32768
+    names = ("hash", "index", "cellStart", "cellEnd", "dens", "P_l", "sumDij")
+    outs = []
+    for flags in (0, capi.FLAG_FULL_SORT | capi.FLAG_NO_FUSION):
+        s = capi.Solver(p, n, solver=IISPH, flags=flags)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.set_max_iterations(6)
+        s.step(3)
+        s.step(4)
+        outs.append(s.download(pressure=True) + tuple(s.get(x) for x in names) + (s.last_iterations,))
+        if flags == 0:
+            assert s.resort_stats() == (6, 0)
+        s.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_edge_cases(hip_lib):
     p = Oracle.default_params(SESPH)
     # empty: stepping an empty solver is a no-op
