@@ -178,10 +178,20 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool packedHashValid = false;
     bool packResort = false; // this pack compacted the previous sorted keys next to the new ones
     uint32_t packChanged = 0; // ... and counted the owned particles that stay but changed cell
+    bool packInplace = false; // the last pack left the owned particles where they were (holesPending until the next reorder)
+    // slab runs, in-place partition: the owned particles are not compacted; dead slots carry the key 0xffffffff
+    DevBuf rsTileDead, rsTileDeadOffset, rsGroupDeadTotal, rsGroupDeadPrefix;
+    hipEvent_t packEvent = nullptr;
+    uint32_t *slabHostTotals = nullptr; // page-locked landing place of the stream totals
+    bool holesPending = false; // posA/velA[0, physN) contain dead slots (keys in hashNext tell which); n counts live ones
+    uint32_t physN = 0;        // physical extent of the arrays while holesPending
     bool rsTilesDirty = false; // rsTileMovers holds counts no scan has consumed
     int clean_tile_counts()
     {
-        if (rsTilesDirty) HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, rsTileMovers.bytes, stream));
+        if (rsTilesDirty) {
+            HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, rsTileMovers.bytes, stream));
+            HIPCHK(hipMemsetAsync(rsTileDead.p, 0, rsTileDead.bytes, stream));
+        }
         rsTilesDirty = false;
         return NRS_OK;
     }
@@ -213,9 +223,12 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
                          &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
-                         &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked};
+                         &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
+                         &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix};
         for (DevBuf *b : all) b->release();
         if (rsEvent) (void)hipEventDestroy(rsEvent);
+        if (packEvent) (void)hipEventDestroy(packEvent);
+        if (slabHostTotals) (void)hipHostFree(slabHostTotals);
         if (rsHostTotal) (void)hipHostFree(rsHostTotal);
         snapshot_release();
         if (ownStream && stream) (void)hipStreamDestroy(stream);
@@ -286,10 +299,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             const size_t mcap = cap / RESORT_MAX_MOVER_DIV + 1;
             NRSCHK(rsMovers.alloc(8 * cap)); NRSCHK(rsMoversAlt.alloc(8 * mcap)); NRSCHK(rsStayers.alloc(8 * cap)); NRSCHK(rsMerged.alloc(8 * cap));
             NRSCHK(rsTileMovers.alloc(4 * nTiles)); NRSCHK(rsTileOffset.alloc(4 * nTiles));
-            NRSCHK(rsGroupTotal.alloc(4 * nGroups)); NRSCHK(rsGroupPrefix.alloc(4 * nGroups)); NRSCHK(rsScalars.alloc(8));
+            NRSCHK(rsGroupTotal.alloc(4 * nGroups)); NRSCHK(rsGroupPrefix.alloc(4 * nGroups)); NRSCHK(rsScalars.alloc(16));
             NRSCHK(rsPrevPacked.alloc(4 * cap));
+            NRSCHK(rsTileDead.alloc(4 * nTiles)); NRSCHK(rsTileDeadOffset.alloc(4 * nTiles));
+            NRSCHK(rsGroupDeadTotal.alloc(4 * nGroups)); NRSCHK(rsGroupDeadPrefix.alloc(4 * nGroups));
+            HIPCHK(hipMemsetAsync(rsTileDead.p, 0, 4 * nTiles, stream));
+            HIPCHK(hipEventCreateWithFlags(&packEvent, hipEventDisableTiming));
             HIPCHK(hipMemsetAsync(rsTileMovers.p, 0, 4 * nTiles, stream));
-            HIPCHK(hipMemsetAsync(rsScalars.p, 0, 8, stream));
+            HIPCHK(hipMemsetAsync(rsScalars.p, 0, 16, stream));
             HIPCHK(hipHostMalloc((void **)&rsHostTotal, 64, hipHostMallocMapped));
             std::memset(rsHostTotal, 0, 64);
             HIPCHK(hipHostGetDevicePointer((void **)&rsHostTotalDev, rsHostTotal, 0));
@@ -337,6 +354,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int upload(const void *pos4, const void *vel4, const void *pres, uint64_t first, uint64_t count) override
     {
         if (first + count > cap) return fail(NRS_E_CAPACITY, "upload exceeds capacity");
+        NRSCHK(compact_holes());
         if (count) {
             if (!pos4) return fail(NRS_E_INVALID, "pos4 is NULL");
             HIPCHK(hipMemcpyAsync(posA.as<T4>() + first, pos4, sizeof(T4) * count, hipMemcpyHostToDevice, stream));
@@ -355,6 +373,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int set_n(uint64_t nn) override
     {
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
+        NRSCHK(compact_holes());
         if (nn != n) { hashReady = false; slotOrderValid = false; }
         n = nn;
         return NRS_OK;
@@ -517,6 +536,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         const uint32_t N = (uint32_t)n;
         const dim3 g(nblocks(N)), b(BLOCK);
+        if (holesPending) { // in-place slab partition: only the merge path can consume arrays with holes
+            const bool canMerge = hashReady && rsPending && rsCountKnown && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT &&
+                                  (uint64_t)rsKnownCount * RESORT_MAX_MOVER_DIV <= n;
+            if (!canMerge) {
+                if (hashReady && rsPending && rsCountKnown) { ++rsSteps; ++rsFallbacks; }
+                NRSCHK(compact_holes()); // also drops the prepared keys: hash and sort from scratch below
+            }
+        }
         uint32_t *kIn = hashA.as<uint32_t>(), *kAlt = hashB.as<uint32_t>();
         uint32_t *vIn = indexA.as<uint32_t>(), *vAlt = indexB.as<uint32_t>();
         if (hashReady) { // keys/values of this step were produced by the previous step's fused force kernel
@@ -529,6 +556,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(ev_end());
         }
         const bool resort = hashReady && rsPending && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT;
+        const bool countKnown = rsCountKnown; // (slab runs: the host already has the mover count)
         hashReady = false;
         rsPending = false;
         rsCountKnown = false;
@@ -541,7 +569,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             // the split of these keys into movers / stayers was queued behind the force kernel; its mover count sizes
             // the mover sort and the merge (see nrs_kernels_resort.h)
             uint32_t M = rsKnownCount;
-            if (!rsCountKnown) NRSCHK(wait_mover_count(&M));
+            if (!countKnown) NRSCHK(wait_mover_count(&M));
             ++rsSteps;
             if ((uint64_t)M * RESORT_MAX_MOVER_DIV <= (uint64_t)N) {
                 if (M == 0) {
@@ -574,6 +602,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_begin(NRS_STAGE_REORDER));
         if (!cellsClean) HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
         cellsClean = false;
+        holesPending = false; // the gather below reads only live slots
         if (merged)
             hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
@@ -586,19 +615,59 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    ResortScan scan_movers() const
+    {
+        uint32_t *sc = rsScalars.as<uint32_t>();
+        return ResortScan{rsTileMovers.as<uint32_t>(), rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc + 1};
+    }
+    ResortScan scan_dead() const
+    {
+        uint32_t *sc = rsScalars.as<uint32_t>();
+        return ResortScan{rsTileDead.as<uint32_t>(), rsTileDeadOffset.as<uint32_t>(), rsGroupDeadTotal.as<uint32_t>(), rsGroupDeadPrefix.as<uint32_t>(), sc + 2};
+    }
+    ResortOffsets offsets_movers() const { return ResortOffsets{rsTileOffset.as<uint32_t>(), rsGroupPrefix.as<uint32_t>()}; }
+    ResortOffsets offsets_dead() const { return ResortOffsets{rsTileDeadOffset.as<uint32_t>(), rsGroupDeadPrefix.as<uint32_t>()}; }
+    int launch_resort_scan(uint32_t nTiles, bool withDead)
+    {
+        const uint32_t nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+        ResortScan none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, scan_movers(), withDead ? scan_dead() : none,
+                           rsScalars.as<uint32_t>(), (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
+        HIPCHK(hipEventRecord(rsEvent, stream));
+        return NRS_OK;
+    }
+    // Somebody wants to look at (or re-partition) the particle arrays while they still have the holes of an in-place slab
+    // partition: compact them now (stable) and forget the prepared re-sort; the next step hashes and sorts from scratch.
+    int compact_holes()
+    {
+        if (!holesPending) return NRS_OK;
+        holesPending = false;
+        const uint32_t NP = physN, nTiles = nblocks(NP);
+        hashReady = false; rsPending = false; rsCountKnown = false; packedHashValid = false;
+        if (!NP) return NRS_OK;
+        NRSCHK(clean_tile_counts());
+        hipLaunchKernelGGL(k_holes_count, dim3(nTiles), dim3(BLOCK), 0, stream, hashNext, rsTileDead.as<uint32_t>(), NP);
+        const uint32_t nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+        ResortScan none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, scan_dead(), none, rsScalars.as<uint32_t>(),
+                           (volatile uint64_t *)nullptr, 0u, nTiles);
+        hipLaunchKernelGGL((k_holes_compact<R>), dim3(nTiles), dim3(BLOCK), 0, stream, hashNext, offsets_dead(), posA.as<T4>(), velA.as<T4>(),
+                           posB.as<T4>(), velB.as<T4>(), NP);
+        HIPCHK(hipGetLastError());
+        std::swap(posA.p, posB.p);
+        std::swap(velA.p, velB.p);
+        return NRS_OK;
+    }
+
     // first half of the next step's sort, queued right behind the kernel that produced the keys in hashNext and counted
     // the movers per tile: scan of the tile counts (total to the host) + stable split into movers / stayers
     int queue_resort_split(uint32_t N)
     {
         NRSCHK(ev_begin(NRS_STAGE_SORT));
-        const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
-        uint32_t *sc = rsScalars.as<uint32_t>();
-        hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
-                           rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
-                           (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
-        HIPCHK(hipEventRecord(rsEvent, stream));
-        hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, rsTileOffset.as<uint32_t>(),
-                           rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+        const uint32_t nTiles = nblocks(N);
+        NRSCHK(launch_resort_scan(nTiles, false));
+        hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(), offsets_movers(),
+                           rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
         rsPending = true;
         NRSCHK(ev_end());
         return NRS_OK;
@@ -672,6 +741,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int reduce_max(int which, double *out) override
     {
         if (!n) { *out = 0; return NRS_OK; }
+        NRSCHK(compact_holes());
         const uint32_t N = (uint32_t)n;
         const uint32_t nbk = std::min<uint32_t>(1024u, nblocks(N));
         if (which == 0)
@@ -795,6 +865,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) override
     {
         if (!nbins || !out) return fail(NRS_E_INVALID, "bad histogram request");
+        NRSCHK(compact_holes());
         DevBuf bins;
         NRSCHK(bins.alloc((size_t)nbins * 4));
         HIPCHK(hipMemsetAsync(bins.p, 0, (size_t)nbins * 4, stream));
@@ -807,22 +878,27 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
-    int slab_pack(void *sendL, void *sendR, uint64_t cap, uint32_t *counts) override
+    int slab_pack(void *sendL, void *sendR, uint64_t mcap, uint32_t *counts) override
     {
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
-        if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
+        if (mcap == 0 || mcap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
+        NRSCHK(compact_holes()); // (a pack right after a pack/unpack without a step in between)
         const uint32_t N = (uint32_t)n;
         const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_TILE - 1) / SLAB_TILE);
         NRSCHK(slabCounts.alloc((size_t)ST_TOTALS * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
         NRSCHK(slabTotals.alloc(ST_TOTALS * 4));
-        NRSCHK(ghostPos.alloc(sizeof(T4) * cap));
-        NRSCHK(ghostVel.alloc(sizeof(T4) * cap));
+        NRSCHK(ghostPos.alloc(sizeof(T4) * mcap));
+        NRSCHK(ghostVel.alloc(sizeof(T4) * mcap));
         uint32_t tot[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
+        bool inplace = false;
         if (N) {
             // coherent re-sort of the next step: possible when the arrays are still in the slot order of the last sort and
             // the fused force kernel left the new keys per slot
             const bool resort = rsMovers.p && slotOrderValid && hashCur && hashNext && hashNext != hashCur;
+            // ... and then the owned particles need not be moved at all (in-place partition, see k_slab_scatter)
+            static const bool allowInplace = !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
+            inplace = resort && allowInplace && (uint64_t)N >= RESORT_MIN_PARTICLES;
             hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
                                slabCounts.as<uint32_t>(), nbk, resort ? hashCur : (const uint32_t *)nullptr,
                                resort ? hashNext : (const uint32_t *)nullptr);
@@ -833,42 +909,80 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             // the hash pass of the next step, done here (into the key buffers the last sort did not end in)
             packKeys = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
             packVals = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+            if (inplace) { packKeys = hashNext; packVals = indexNext; } // the fused kernel's keys / slot numbers stay where they are
             out.hash = packKeys; out.index = packVals;
             out.prevHash = resort ? hashCur : nullptr;
-            out.prevPacked = resort ? rsPrevPacked.as<uint32_t>() : nullptr;
+            out.prevPacked = (resort && !inplace) ? rsPrevPacked.as<uint32_t>() : nullptr;
             out.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
+            out.tileDead = inplace ? rsTileDead.as<uint32_t>() : nullptr;
             if (resort) NRSCHK(clean_tile_counts());
             rsTilesDirty = resort;
             packResort = resort;
             out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
             out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
-            out.cap = (uint32_t)cap;
-            hipLaunchKernelGGL((k_slab_scatter<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
-                               slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+            out.cap = (uint32_t)mcap;
+            if (inplace)
+                hipLaunchKernelGGL((k_slab_scatter<R, true>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
+                                   slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+            else
+                hipLaunchKernelGGL((k_slab_scatter<R, false>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
+                                   slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
             hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
                                (unsigned char *)sendR);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(tot, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
+            // page-locked destination: the copy is complete when the event behind it is (a pageable destination is only
+            // guaranteed after a stream synchronization, which would also wait for the split queued below)
+            if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 64, hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+            if (inplace) {
+                // the split of the slots we keep does not depend on what arrives: queue it now, so that it runs while the
+                // host reads the totals and the messages travel
+                HIPCHK(hipEventRecord(packEvent, stream));
+                const uint32_t nTiles = nblocks(N);
+                NRSCHK(launch_resort_scan(nTiles, true));
+                hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
+                                   offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                HIPCHK(hipGetLastError());
+                rsTilesDirty = false; // the scan resets the counts it reads
+                HIPCHK(hipEventSynchronize(packEvent));
+            } else {
+                HIPCHK(hipStreamSynchronize(stream));
+            }
+            std::memcpy(tot, slabHostTotals, sizeof(tot));
         } else {
             HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_TOTALS * 4, stream));
             hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
                                (unsigned char *)sendR);
             HIPCHK(hipStreamSynchronize(stream));
         }
-        if ((uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > cap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > cap || tot[ST_GHOST] > cap)
-            return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
-        if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
-        else { packKeys = hashA.as<uint32_t>(); packVals = indexA.as<uint32_t>(); packResort = false; }
+        if ((uint64_t)tot[ST_STAY] + tot[ST_MIG_L] + tot[ST_MIG_R] > N || tot[ST_CHANGED] > tot[ST_STAY])
+            return fail(NRS_E_HIP, "inconsistent slab stream totals");
+        const bool overflow = (uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > mcap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > mcap ||
+                              tot[ST_GHOST] > mcap;
         hashReady = false;
         rsPending = false;
+        rsCountKnown = false;
         slotOrderValid = false;
-        packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
+        if (inplace) {
+            holesPending = true;
+            physN = N;
+            packedHashValid = true; // hashNext / indexNext hold key and slot of every live slot, 0xffffffff marks the dead ones
+            rsPending = true;
+            rsCountKnown = true;
+            rsKnownCount = tot[ST_CHANGED]; // arrivals are added by nrs_slab_unpack
+            hashReady = true;
+        } else {
+            if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
+            else { packKeys = hashA.as<uint32_t>(); packVals = indexA.as<uint32_t>(); packResort = false; }
+            packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
+        }
+        packInplace = inplace;
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];
         packChanged = tot[ST_CHANGED];
         if (counts) std::memcpy(counts, tot, ST_COUNT * sizeof(uint32_t));
+        if (overflow) return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
         return NRS_OK;
     }
     uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_TILE - 1) / SLAB_TILE); }
@@ -881,8 +995,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (recvR) HIPCHK(hipMemcpyAsync(hR, recvR, 16, hipMemcpyDeviceToHost, stream));
         if (recvL || recvR) HIPCHK(hipStreamSynchronize(stream));
         if ((uint64_t)hL[0] + hL[1] > mcap || (uint64_t)hR[0] + hR[1] > mcap) return fail(NRS_E_INVALID, "corrupt slab message header");
-        const uint64_t total = n + hL[0] + hR[0] + ghostCount + hL[1] + hR[1];
-        if (total > cap) return fail(NRS_E_CAPACITY, "owned + halo particles exceed the context capacity");
+        const bool inplace = packInplace && holesPending;
+        const uint64_t arrivals = (uint64_t)hL[0] + hR[0] + ghostCount + hL[1] + hR[1];
+        const uint64_t total = n + arrivals;                           // live particles of the next step
+        const uint64_t base = inplace ? (uint64_t)physN : (uint64_t)n; // first free physical slot
+        if (base + arrivals > cap) return fail(NRS_E_CAPACITY, "owned + halo particles exceed the context capacity");
         const unsigned char *bL = (const unsigned char *)recvL, *bR = (const unsigned char *)recvR;
         auto mp = [&](const unsigned char *b) { return (const T4 *)(b + 16); };
         auto mv = [&](const unsigned char *b) { return (const T4 *)(b + 16 + (size_t)mcap * sizeof(T4)); };
@@ -895,27 +1012,29 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         A.srcPos[4] = bR ? mp(bR) + hR[0] : nullptr;   A.srcVel[4] = bR ? mv(bR) + hR[0] : nullptr;    // halo from the right
         A.start[0] = 0;
         for (int k = 0; k < 5; ++k) A.start[k + 1] = A.start[k] + len[k];
+        const bool compactResort = !inplace && packResort;
         if (A.start[5])
             hipLaunchKernelGGL((k_slab_append<R>), dim3((A.start[5] + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, stream, P, A,
-                               posA.as<T4>(), velA.as<T4>(), packKeys, packVals, packResort ? rsPrevPacked.as<uint32_t>() : (uint32_t *)nullptr,
-                               packResort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr, (uint32_t)n);
+                               posA.as<T4>(), velA.as<T4>(), packKeys, packVals,
+                               compactResort ? rsPrevPacked.as<uint32_t>() : (uint32_t *)nullptr,
+                               compactResort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr, (uint32_t)base,
+                               inplace ? rsMovers.as<uint64_t>() : (uint64_t *)nullptr, inplace ? rsKnownCount : 0u);
         HIPCHK(hipGetLastError());
         nOwned = n + hL[0] + hR[0];
         n = total;
         // pack + unpack have written the radix keys/values of every local particle
         hashNext = packKeys; indexNext = packVals;
         hashReady = packedHashValid;
-        if (hashReady && packResort && n >= RESORT_MIN_PARTICLES) {
+        if (inplace) {
+            physN += (uint32_t)arrivals;
+            rsKnownCount += (uint32_t)arrivals; // every arrival is a mover (k_slab_append put it behind the cell changers)
+        } else if (hashReady && packResort && n >= RESORT_MIN_PARTICLES) {
             // coherent re-sort: the owned particles that stayed in their cell are still in sorted order
-            const uint32_t N = (uint32_t)n, nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
-            uint32_t *sc = rsScalars.as<uint32_t>();
             // (the partition and the append have counted the movers of every tile of the new arrays)
-            hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, rsTileMovers.as<uint32_t>(),
-                               rsTileOffset.as<uint32_t>(), rsGroupTotal.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), sc, sc + 1,
-                               (volatile uint64_t *)rsHostTotalDev, ++rsSeq, nTiles);
-            HIPCHK(hipEventRecord(rsEvent, stream));
-            hipLaunchKernelGGL(k_resort_split, dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
-                               rsTileOffset.as<uint32_t>(), rsGroupPrefix.as<uint32_t>(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+            const uint32_t N = (uint32_t)n, nTiles = nblocks(N);
+            NRSCHK(launch_resort_scan(nTiles, false));
+            hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
+                               offsets_movers(), offsets_movers(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
             rsPending = true;
             rsCountKnown = true; // everything appended is a mover, and the partition counted the cell changers
             rsKnownCount = packChanged + A.start[5];
@@ -1015,6 +1134,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int snapshot_begin(int withVel) override
     {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
+        NRSCHK(compact_holes());
         if (!copyStream) HIPCHK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
         Snap &sn = snaps[snapHead];
         if (sn.pending) { // both slots in flight: the oldest is this one
@@ -1071,6 +1191,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int download(void *pos4, void *vel4, void *pres) override
     {
+        NRSCHK(compact_holes());
         if (pos4) HIPCHK(hipMemcpyAsync(pos4, posA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
         if (vel4) HIPCHK(hipMemcpyAsync(vel4, velA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
         if (pres) HIPCHK(hipMemcpyAsync(pres, presA.p, sizeof(R) * n, hipMemcpyDeviceToHost, stream));
@@ -1079,6 +1200,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     }
     int array(int which, void **dptr, uint64_t *bytes) override
     {
+        if (which == NRS_ARR_POS || which == NRS_ARR_VEL) NRSCHK(compact_holes());
         const uint64_t v = sizeof(T4) * n, s = sizeof(R) * n, u = 4 * n, c = 4ull * P.numCells;
         void *p = nullptr;
         uint64_t sz = 0;

@@ -29,13 +29,14 @@ constexpr uint64_t RESORT_MAX_MOVER_DIV = 8;     // more than N/8 movers: full r
 // Exclusive scan of the per-tile mover counts, two levels: every workgroup scans RESORT_GROUP counts (coalesced; the
 // counts are reset to 0 for the next step's atomics) and the last one to finish scans the group totals.
 // tileOffset[t] is local to the group; groupPrefix[t / RESORT_GROUP] is added by the consumer.
-__global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__restrict__ tileMovers,
-                                                                     uint32_t *__restrict__ tileOffset,
-                                                                     uint32_t *__restrict__ groupTotal,
-                                                                     uint32_t *__restrict__ groupPrefix, uint32_t *__restrict__ done,
-                                                                     uint32_t *__restrict__ total, volatile uint64_t *hostTotal,
-                                                                     uint32_t seq, uint32_t nTiles)
+struct ResortScan { // one scanned array: counts in, offsets (local to the group) + group totals/prefixes out
+    uint32_t *tile, *tileOffset, *groupTotal, *groupPrefix, *total;
+};
+__global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(ResortScan a, ResortScan b, uint32_t *__restrict__ done,
+                                                                     volatile uint64_t *hostTotal, uint32_t seq, uint32_t nTiles)
 {
+    // a = movers (always), b = dead slots (slab runs that leave holes; b.tile == nullptr otherwise).  The total of `a`
+    // goes to the host.
     __shared__ uint32_t waveSum[RESORT_GROUP / 64];
     __shared__ bool last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -54,13 +55,17 @@ __global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__
         return base + inc - v;
     };
     const uint32_t t = blockIdx.x * RESORT_GROUP + tid;
-    uint32_t v = 0;
-    if (t < nTiles) { v = tileMovers[t]; tileMovers[t] = 0; }
-    uint32_t sum;
-    const uint32_t ex = block_exclusive(v, sum);
-    if (t < nTiles) tileOffset[t] = ex;
+    const ResortScan arr[2] = {a, b};
+    for (int k = 0; k < 2; ++k) {
+        if (!arr[k].tile) continue;
+        uint32_t v = 0;
+        if (t < nTiles) { v = arr[k].tile[t]; arr[k].tile[t] = 0; }
+        uint32_t sum;
+        const uint32_t ex = block_exclusive(v, sum);
+        if (t < nTiles) arr[k].tileOffset[t] = ex;
+        if (tid == 0) arr[k].groupTotal[blockIdx.x] = sum;
+    }
     if (tid == 0) {
-        groupTotal[blockIdx.x] = sum;
         __threadfence();
         last = atomicAdd(done, 1u) == gridDim.x - 1;
     }
@@ -68,52 +73,84 @@ __global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(uint32_t *__
     if (!last) return;
     __threadfence();
     // gridDim.x <= RESORT_GROUP (checked by the host): one more scan over the group totals
-    const uint32_t g = tid < gridDim.x ? __atomic_load_n(&groupTotal[tid], __ATOMIC_RELAXED) : 0u;
-    uint32_t all;
-    const uint32_t gex = block_exclusive(g, all);
-    if (tid < gridDim.x) groupPrefix[tid] = gex;
-    if (tid == 0) {
-        *total = all;
-        if (hostTotal) *hostTotal = ((uint64_t)seq << 32) | all; // one 8-byte store to mapped host memory: (launch number, count)
-        *done = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!arr[k].tile) continue;
+        const uint32_t g = tid < gridDim.x ? __atomic_load_n(&arr[k].groupTotal[tid], __ATOMIC_RELAXED) : 0u;
+        uint32_t all;
+        const uint32_t gex = block_exclusive(g, all);
+        if (tid < gridDim.x) arr[k].groupPrefix[tid] = gex;
+        if (tid == 0) {
+            *arr[k].total = all;
+            if (k == 0 && hostTotal) *hostTotal = ((uint64_t)seq << 32) | all; // one 8-byte store to mapped host memory: (launch number, count)
+        }
     }
+    if (tid == 0) *done = 0;
 }
 
-// movers per tile when no force kernel counted them (slab runs: the arrays were re-partitioned in between; prevHash
-// is 0xffffffff for slots that were appended, so they always count as movers)
-__global__ __launch_bounds__(BLOCK) void k_resort_count(const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash,
-                                                        uint32_t *__restrict__ tileMovers, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool mover = i < n && prevHash[i] != nextHash[i];
-    const uint64_t mask = __ballot(mover);
-    if ((threadIdx.x & 63u) == 0 && mask) atomicAdd(&tileMovers[blockIdx.x], (uint32_t)__popcll(mask));
-}
-
-// stable split of slot i (tile = i / BLOCK) by "hash changed": movers[rank among movers], stayers[rank among stayers]
+// stable split of slot i (tile = i / BLOCK) by "hash changed": movers[rank among movers], stayers[rank among stayers].
+// HOLES (slab runs that do not compact their arrays): a slot whose next key is 0xffffffff is dead (its particle left
+// the slab or was a halo copy) and goes to neither list; `dead` holds the scanned per-tile counts of such slots.
+struct ResortOffsets { const uint32_t *tileOffset, *groupPrefix; };
+template <bool HOLES>
 __global__ __launch_bounds__(BLOCK) void k_resort_split(const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash,
-                                                        const uint32_t *__restrict__ tileOffset,
-                                                        const uint32_t *__restrict__ groupPrefix, uint64_t *__restrict__ movers,
+                                                        ResortOffsets mov, ResortOffsets dead, uint64_t *__restrict__ movers,
                                                         uint64_t *__restrict__ stayers, uint32_t n)
 {
-    __shared__ uint32_t waveCount[BLOCK / 64];
+    __shared__ uint32_t waveCount[2][BLOCK / 64];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t i = tile * BLOCK + tid;
     const bool live = i < n;
     uint32_t k = 0;
-    bool mover = false;
-    if (live) { k = nextHash[i]; mover = k != prevHash[i]; }
-    const uint64_t mask = __ballot(mover);
+    bool mover = false, hole = false;
+    if (live) {
+        k = nextHash[i];
+        hole = HOLES && k == 0xffffffffu;
+        mover = !hole && k != prevHash[i];
+    }
+    const uint64_t mask = __ballot(mover), hmask = HOLES ? __ballot(hole) : 0ull;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    if (lane == 0) waveCount[wave] = (uint32_t)__popcll(mask);
+    if (lane == 0) { waveCount[0][wave] = (uint32_t)__popcll(mask); waveCount[1][wave] = (uint32_t)__popcll(hmask); }
     __syncthreads();
-    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    for (uint32_t w = 0; w < wave; ++w) before += waveCount[w];
-    if (!live) return;
-    const uint32_t moversBefore = groupPrefix[tile / RESORT_GROUP] + tileOffset[tile] + before;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t before = (uint32_t)__popcll(mask & below), hbefore = (uint32_t)__popcll(hmask & below);
+    for (uint32_t w = 0; w < wave; ++w) { before += waveCount[0][w]; hbefore += waveCount[1][w]; }
+    if (!live || hole) return;
+    const uint32_t moversBefore = mov.groupPrefix[tile / RESORT_GROUP] + mov.tileOffset[tile] + before;
+    const uint32_t holesBefore = HOLES ? dead.groupPrefix[tile / RESORT_GROUP] + dead.tileOffset[tile] + hbefore : 0u;
     const uint64_t e = ((uint64_t)k << 32) | i;
     if (mover) movers[moversBefore] = e;
-    else stayers[i - moversBefore] = e;
+    else stayers[i - moversBefore - holesBefore] = e;
+}
+
+// stable compaction of (pos, vel) by "slot is live", used when somebody looks at the arrays while they have holes
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_holes_compact(const uint32_t *__restrict__ keys, ResortOffsets dead,
+                                                         const typename Vec4T<R>::type *__restrict__ pos,
+                                                         const typename Vec4T<R>::type *__restrict__ vel,
+                                                         typename Vec4T<R>::type *__restrict__ outPos,
+                                                         typename Vec4T<R>::type *__restrict__ outVel, uint32_t n)
+{
+    __shared__ uint32_t waveCount[BLOCK / 64];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t i = tile * BLOCK + tid;
+    const bool hole = i < n && keys[i] == 0xffffffffu;
+    const uint64_t hmask = __ballot(hole);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0) waveCount[wave] = (uint32_t)__popcll(hmask);
+    __syncthreads();
+    uint32_t hbefore = (uint32_t)__popcll(hmask & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) hbefore += waveCount[w];
+    if (i >= n || hole) return;
+    const uint32_t d = i - (dead.groupPrefix[tile / RESORT_GROUP] + dead.tileOffset[tile] + hbefore);
+    outPos[d] = pos[i];
+    outVel[d] = vel[i];
+}
+// per-tile count of dead slots (input of the scan that k_holes_compact needs)
+__global__ __launch_bounds__(BLOCK) void k_holes_count(const uint32_t *__restrict__ keys, uint32_t *__restrict__ tileDead, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t m = __ballot(i < n && keys[i] == 0xffffffffu);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&tileDead[blockIdx.x], (uint32_t)__popcll(m));
 }
 
 // reorderDataAndFindCellStartD (sph_kernel_impl.cuh:210-281) fed by the merged u64 pairs; also writes the plain

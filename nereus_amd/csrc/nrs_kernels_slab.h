@@ -106,6 +106,8 @@ template <typename R> struct SlabOut {
     const uint32_t *prevHash; // sorted keys of the step that produced `pos` (slot order), or null
     uint32_t *prevPacked;     // their compacted copy for the coherent re-sort (nrs_kernels_resort.h), or null
     uint32_t *tileMovers;     // with prevPacked: per 256-slot tile of the COMPACTED array, slots whose key changed
+    // INPLACE partition (owned particles are not moved; `hash` holds the keys the fused force kernel computed per slot):
+    uint32_t *tileDead;       // per 256-slot tile: slots that hold no particle of the next step (left, or old halo copy)
     T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
     unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
     uint32_t cap;            // particles per message buffer
@@ -117,8 +119,11 @@ template <typename R> NRS_DEV typename Vec4T<R>::type *msg_vel(unsigned char *bu
     return (typename Vec4T<R>::type *)(buf + 16 + (size_t)cap * sizeof(typename Vec4T<R>::type));
 }
 
-// pass 3: stable scatter of every stream (also hashes the particles that stay, for the next step's sort)
-template <typename R>
+// pass 3: stable scatter of every stream (also hashes the particles that stay, for the next step's sort).
+// INPLACE: the particles that stay are not moved at all — their slot keeps its key (out.hash[i], computed by the fused
+// force kernel), dead slots get the key 0xffffffff, and the per-tile counts of cell changers / dead slots feed the
+// coherent re-sort (nrs_kernels_resort.h), whose merged order then skips the holes.
+template <typename R, bool INPLACE>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
                                                             const typename Vec4T<R>::type *__restrict__ vel, uint32_t n,
                                                             const uint32_t *__restrict__ blockOffsets, uint32_t nBlocks,
@@ -141,6 +146,14 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
             if (lane == 0) waveCnt[s][wave] = (uint32_t)__popcll(m);
         }
         __syncthreads();
+        if (INPLACE && i < n) {
+            if (!(f & (1u << ST_STAY))) {
+                out.hash[i] = 0xffffffffu;
+                atomicAdd(&out.tileDead[i / SLAB_BLOCK], 1u);
+            } else if (out.hash[i] != out.prevHash[i]) {
+                atomicAdd(&out.tileMovers[i / SLAB_BLOCK], 1u);
+            }
+        }
         if (f) {
             T4 tagged = p;
             tagged.w = (R)2; // read-only copy
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
                 for (uint32_t w = 0; w < wave; ++w) idx += waveCnt[s][w];
                 switch (s) {
                 case ST_STAY: {
+                    if (INPLACE) break;
                     out.stayPos[idx] = p; out.stayVel[idx] = v;
                     const I3 g = calcGridPos<R>(P, xyz<R>(p));
                     const uint32_t key = calcGridHash<R>(P, g.x, g.y, g.z);
@@ -226,7 +240,8 @@ template <typename R>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendPieces<R> A, typename Vec4T<R>::type *__restrict__ dstPos,
                                                            typename Vec4T<R>::type *__restrict__ dstVel, uint32_t *__restrict__ hash,
                                                            uint32_t *__restrict__ index, uint32_t *__restrict__ prevPacked,
-                                                           uint32_t *__restrict__ tileMovers, uint32_t dstBase)
+                                                           uint32_t *__restrict__ tileMovers, uint32_t dstBase,
+                                                           uint64_t *__restrict__ movers, uint32_t moverBase)
 {
     const uint32_t i = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (i >= A.start[5]) return;
@@ -237,8 +252,11 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_append(Params<R> P, AppendP
     dstPos[dstBase + i] = p;
     dstVel[dstBase + i] = A.srcVel[k][j];
     const I3 g = calcGridPos<R>(P, xyz<R>(p));
-    hash[dstBase + i] = calcGridHash<R>(P, g.x, g.y, g.z);
+    const uint32_t key = calcGridHash<R>(P, g.x, g.y, g.z);
+    hash[dstBase + i] = key;
     index[dstBase + i] = dstBase + i;
+    // in-place partition: every arrival goes straight to the tail of the mover list of the coherent re-sort
+    if (movers) movers[moverBase + i] = ((uint64_t)key << 32) | (dstBase + i);
     if (prevPacked) { // new to this rank's arrays: never a "stayer" of the coherent re-sort
         prevPacked[dstBase + i] = 0xffffffffu;
         atomicAdd(&tileMovers[(dstBase + i) / SLAB_BLOCK], 1u);

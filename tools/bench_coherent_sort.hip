@@ -151,10 +151,11 @@ int main(int argc, char **argv)
         size_t b = tmpBytes;
         k_count<<<nTiles, 256, 0, st>>>(dOld, dNext, dTileMovers, n);
         CHK(hipEventRecord(ev[0], st));
-        nrs::k_resort_scan_tiles<<<nGroups, nrs::RESORT_GROUP, 0, st>>>(dTileMovers, dTileOffset, dGroupTotal, dGroupPrefix, dDone, dCount,
-                                                                         hTotalDev, (uint32_t)(r + 1), nTiles);
+        const nrs::ResortScan sc = {dTileMovers, dTileOffset, dGroupTotal, dGroupPrefix, dCount}, none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        nrs::k_resort_scan_tiles<<<nGroups, nrs::RESORT_GROUP, 0, st>>>(sc, none, dDone, hTotalDev, (uint32_t)(r + 1), nTiles);
         CHK(hipEventRecord(evM, st));
-        nrs::k_resort_split<<<nTiles, 256, 0, st>>>(dOld, dNext, dTileOffset, dGroupPrefix, dMov, dStay, n);
+        const nrs::ResortOffsets off = {dTileOffset, dGroupPrefix};
+        nrs::k_resort_split<false><<<nTiles, 256, 0, st>>>(dOld, dNext, off, off, dMov, dStay, n);
         CHK(hipEventRecord(ev[1], st));
         CHK(hipEventSynchronize(evM));
         const uint32_t M = (uint32_t)*hTotal;
