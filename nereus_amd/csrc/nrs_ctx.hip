@@ -179,6 +179,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool packResort = false; // this pack compacted the previous sorted keys next to the new ones
     uint32_t packChanged = 0; // ... and counted the owned particles that stay but changed cell
     bool packInplace = false; // the last pack left the owned particles where they were (holesPending until the next reorder)
+    // fused classification: the force kernel of the last step already wrote stream flags / counts / dead marks for these cuts
+    DevBuf slabFlags;
+    bool classifiedValid = false;
+    uint32_t classifiedN = 0;
     // slab runs, in-place partition: the owned particles are not compacted; dead slots carry the key 0xffffffff
     DevBuf rsTileDead, rsTileDeadOffset, rsGroupDeadTotal, rsGroupDeadPrefix;
     hipEvent_t packEvent = nullptr;
@@ -224,7 +228,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
                          &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
-                         &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix};
+                         &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
         if (rsEvent) (void)hipEventDestroy(rsEvent);
         if (packEvent) (void)hipEventDestroy(packEvent);
@@ -704,9 +708,29 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             fo.hash = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
             fo.index = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
             const bool resort = rsMovers.p && !slabOn && (uint64_t)N >= RESORT_MIN_PARTICLES;
-            if (resort) NRSCHK(clean_tile_counts());
-            fo.prevHash = resort ? hashCur : nullptr;
-            fo.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
+            // slab runs: the next partition's classification rides in the same launch (k_slab_count and most of
+            // k_slab_scatter then have nothing left to do)
+            static const bool allowFusedSlab = !(getenv("NEREUS_SLAB_FUSED") && atoi(getenv("NEREUS_SLAB_FUSED")) == 0) &&
+                                               !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
+            const bool classify = rsMovers.p && slabOn && allowFusedSlab && (uint64_t)N >= RESORT_MIN_PARTICLES;
+            if (resort || classify) NRSCHK(clean_tile_counts());
+            fo.prevHash = (resort || classify) ? hashCur : nullptr;
+            fo.tileMovers = (resort || classify) ? rsTileMovers.as<uint32_t>() : nullptr;
+            fo.slabFlags = nullptr; fo.slabBlockCounts = nullptr; fo.slabBlocks = 0; fo.tileDead = nullptr; fo.slab = slab;
+            classifiedValid = false;
+            if (classify) {
+                const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_TILE - 1) / SLAB_TILE);
+                NRSCHK(slabFlags.alloc(cap));
+                NRSCHK(slabCounts.alloc((size_t)ST_TOTALS * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
+                HIPCHK(hipMemsetAsync(slabCounts.p, 0, (size_t)ST_TOTALS * nbk * 4, stream));
+                fo.slabFlags = slabFlags.as<uint8_t>();
+                fo.slabBlockCounts = slabCounts.as<uint32_t>();
+                fo.slabBlocks = nbk;
+                fo.tileDead = rsTileDead.as<uint32_t>();
+                classifiedValid = true;
+                classifiedN = N;
+                rsTilesDirty = true; // until a pack's scan consumes the tile counts
+            }
             launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
                                                       velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
             hashNext = fo.hash; indexNext = fo.index;
@@ -856,6 +880,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (iisph()) return fail(NRS_E_STATE, "slab decomposition is implemented for the SESPH solver only");
         if (halo < 2) return fail(NRS_E_INVALID, "halo must be >= 2 cells (one cell for the density of the ring + one)");
         if ((long long)hi - lo < 2ll * halo) return fail(NRS_E_INVALID, "slab narrower than two halos");
+        if (classifiedValid && (slab.lo != lo || slab.hi != hi || slab.halo != halo)) {
+            // the last force kernel classified (and marked dead keys) for the old cuts: partition the slow way once
+            classifiedValid = false;
+            slotOrderValid = false;
+        }
         slab.lo = lo; slab.hi = hi; slab.halo = halo;
         slabOn = true;
         nOwned = n;
@@ -893,62 +922,103 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         uint32_t tot[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
         bool inplace = false;
         if (N) {
-            // coherent re-sort of the next step: possible when the arrays are still in the slot order of the last sort and
-            // the fused force kernel left the new keys per slot
-            const bool resort = rsMovers.p && slotOrderValid && hashCur && hashNext && hashNext != hashCur;
-            // ... and then the owned particles need not be moved at all (in-place partition, see k_slab_scatter)
-            static const bool allowInplace = !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
-            inplace = resort && allowInplace && (uint64_t)N >= RESORT_MIN_PARTICLES;
-            hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
-                               slabCounts.as<uint32_t>(), nbk, resort ? hashCur : (const uint32_t *)nullptr,
-                               resort ? hashNext : (const uint32_t *)nullptr);
-            hipLaunchKernelGGL(k_slab_scan, dim3(ST_TOTALS), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
-                               slabTotals.as<uint32_t>());
-            SlabOut<R> out;
-            out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
-            // the hash pass of the next step, done here (into the key buffers the last sort did not end in)
-            packKeys = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
-            packVals = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
-            if (inplace) { packKeys = hashNext; packVals = indexNext; } // the fused kernel's keys / slot numbers stay where they are
-            out.hash = packKeys; out.index = packVals;
-            out.prevHash = resort ? hashCur : nullptr;
-            out.prevPacked = (resort && !inplace) ? rsPrevPacked.as<uint32_t>() : nullptr;
-            out.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
-            out.tileDead = inplace ? rsTileDead.as<uint32_t>() : nullptr;
-            if (resort) NRSCHK(clean_tile_counts());
-            rsTilesDirty = resort;
-            packResort = resort;
-            out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
-            out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
-            out.cap = (uint32_t)mcap;
-            if (inplace)
-                hipLaunchKernelGGL((k_slab_scatter<R, true>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
-                                   slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
-            else
-                hipLaunchKernelGGL((k_slab_scatter<R, false>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
-                                   slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
-            hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
-                               (unsigned char *)sendR);
-            HIPCHK(hipGetLastError());
-            // page-locked destination: the copy is complete when the event behind it is (a pageable destination is only
-            // guaranteed after a stream synchronization, which would also wait for the split queued below)
             if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 64, hipHostMallocDefault));
-            HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
-            if (inplace) {
-                // the split of the slots we keep does not depend on what arrives: queue it now, so that it runs while the
-                // host reads the totals and the messages travel
-                HIPCHK(hipEventRecord(packEvent, stream));
+            const bool fusedClass = classifiedValid && slotOrderValid && classifiedN == N && rsMovers.p && hashCur && hashNext &&
+                                    hashNext != hashCur;
+            if (fusedClass) {
+                // the force kernel of the last step classified every slot for these cuts (flags, stream populations per
+                // 2048 slots, dead marks in the keys, movers / dead per 256 slots): scan, copy out the few particles of
+                // the message and ghost streams, split
+                inplace = true;
+                packResort = true;
+                packKeys = hashNext; packVals = indexNext;
+                hipLaunchKernelGGL(k_slab_scan, dim3(ST_TOTALS), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
+                                   slabTotals.as<uint32_t>());
+                SlabOut<R> out;
+                out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
+                out.hash = packKeys; out.index = packVals;
+                out.prevHash = hashCur; out.prevPacked = nullptr;
+                out.tileMovers = rsTileMovers.as<uint32_t>(); out.tileDead = rsTileDead.as<uint32_t>();
+                out.flags = slabFlags.as<uint8_t>();
+                out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
+                out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
+                out.cap = (uint32_t)mcap;
+                hipLaunchKernelGGL((k_slab_scatter<R, true, true>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(),
+                                   velA.as<T4>(), N, slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+                hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
+                                   (unsigned char *)sendR);
                 const uint32_t nTiles = nblocks(N);
-                NRSCHK(launch_resort_scan(nTiles, true));
+                NRSCHK(launch_resort_scan(nTiles, true)); // also totals the cell changers and the dead slots
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(slabHostTotals + 8, rsScalars.p, 16, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipEventRecord(packEvent, stream));
                 hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
                                    offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
                 HIPCHK(hipGetLastError());
                 rsTilesDirty = false; // the scan resets the counts it reads
                 HIPCHK(hipEventSynchronize(packEvent));
+                std::memcpy(tot, slabHostTotals, sizeof(tot));
+                tot[ST_CHANGED] = slabHostTotals[8 + 1];
+                tot[ST_STAY] = N - slabHostTotals[8 + 2];
             } else {
-                HIPCHK(hipStreamSynchronize(stream));
+                // coherent re-sort of the next step: possible when the arrays are still in the slot order of the last sort and
+                // the fused force kernel left the new keys per slot
+                const bool resort = rsMovers.p && slotOrderValid && hashCur && hashNext && hashNext != hashCur;
+                // ... and then the owned particles need not be moved at all (in-place partition, see k_slab_scatter)
+                static const bool allowInplace = !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
+                inplace = resort && allowInplace && (uint64_t)N >= RESORT_MIN_PARTICLES;
+                hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
+                                   slabCounts.as<uint32_t>(), nbk, resort ? hashCur : (const uint32_t *)nullptr,
+                                   resort ? hashNext : (const uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_slab_scan, dim3(ST_TOTALS), dim3(SLAB_BLOCK), 0, stream, slabCounts.as<uint32_t>(), nbk,
+                                   slabTotals.as<uint32_t>());
+                SlabOut<R> out;
+                out.stayPos = posB.as<T4>(); out.stayVel = velB.as<T4>();
+                // the hash pass of the next step, done here (into the key buffers the last sort did not end in)
+                packKeys = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+                packVals = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+                if (inplace) { packKeys = hashNext; packVals = indexNext; } // the fused kernel's keys / slot numbers stay where they are
+                out.hash = packKeys; out.index = packVals;
+                out.prevHash = resort ? hashCur : nullptr;
+                out.prevPacked = (resort && !inplace) ? rsPrevPacked.as<uint32_t>() : nullptr;
+                out.tileMovers = resort ? rsTileMovers.as<uint32_t>() : nullptr;
+                out.tileDead = inplace ? rsTileDead.as<uint32_t>() : nullptr;
+                if (resort) NRSCHK(clean_tile_counts());
+                if (resort) rsTilesDirty = true; // (never clear it here: the counts of an unused classification may still be in the arrays)
+                packResort = resort;
+                out.ghostPos = ghostPos.as<T4>(); out.ghostVel = ghostVel.as<T4>();
+                out.sendL = (unsigned char *)sendL; out.sendR = (unsigned char *)sendR;
+                out.cap = (uint32_t)mcap;
+                if (inplace)
+                    hipLaunchKernelGGL((k_slab_scatter<R, true>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
+                                       slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+                else
+                    hipLaunchKernelGGL((k_slab_scatter<R, false>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), velA.as<T4>(), N,
+                                       slabCounts.as<uint32_t>(), nbk, slabTotals.as<uint32_t>(), out);
+                hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
+                                   (unsigned char *)sendR);
+                HIPCHK(hipGetLastError());
+                // page-locked destination: the copy is complete when the event behind it is (a pageable destination is only
+                // guaranteed after a stream synchronization, which would also wait for the split queued below)
+                if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 64, hipHostMallocDefault));
+                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+                if (inplace) {
+                    // the split of the slots we keep does not depend on what arrives: queue it now, so that it runs while the
+                    // host reads the totals and the messages travel
+                    HIPCHK(hipEventRecord(packEvent, stream));
+                    const uint32_t nTiles = nblocks(N);
+                    NRSCHK(launch_resort_scan(nTiles, true));
+                    hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
+                                       offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                    HIPCHK(hipGetLastError());
+                    rsTilesDirty = false; // the scan resets the counts it reads
+                    HIPCHK(hipEventSynchronize(packEvent));
+                } else {
+                    HIPCHK(hipStreamSynchronize(stream));
+                }
+                std::memcpy(tot, slabHostTotals, sizeof(tot));
             }
-            std::memcpy(tot, slabHostTotals, sizeof(tot));
         } else {
             HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_TOTALS * 4, stream));
             hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
@@ -977,6 +1047,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
         }
         packInplace = inplace;
+        classifiedValid = false;
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];

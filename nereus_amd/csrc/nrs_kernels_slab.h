@@ -108,6 +108,7 @@ template <typename R> struct SlabOut {
     uint32_t *tileMovers;     // with prevPacked: per 256-slot tile of the COMPACTED array, slots whose key changed
     // INPLACE partition (owned particles are not moved; `hash` holds the keys the fused force kernel computed per slot):
     uint32_t *tileDead;       // per 256-slot tile: slots that hold no particle of the next step (left, or old halo copy)
+    const uint8_t *flags;     // FROM_FLAGS: stream flags per slot, written by the fused force kernel of the step
     T4 *ghostPos, *ghostVel; // our read-only copies of fresh migrants
     unsigned char *sendL, *sendR; // message buffers (may be null at the ends of the chain)
     uint32_t cap;            // particles per message buffer
@@ -123,7 +124,9 @@ template <typename R> NRS_DEV typename Vec4T<R>::type *msg_vel(unsigned char *bu
 // INPLACE: the particles that stay are not moved at all — their slot keeps its key (out.hash[i], computed by the fused
 // force kernel), dead slots get the key 0xffffffff, and the per-tile counts of cell changers / dead slots feed the
 // coherent re-sort (nrs_kernels_resort.h), whose merged order then skips the holes.
-template <typename R, bool INPLACE>
+// FROM_FLAGS (with INPLACE): the fused force kernel has already classified every slot, marked the dead ones and
+// counted the streams; only the particles of the message / ghost streams are touched here.
+template <typename R, bool INPLACE, bool FROM_FLAGS = false>
 __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCfg c, const typename Vec4T<R>::type *__restrict__ pos,
                                                             const typename Vec4T<R>::type *__restrict__ vel, uint32_t n,
                                                             const uint32_t *__restrict__ blockOffsets, uint32_t nBlocks,
@@ -138,7 +141,14 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
         const uint32_t i = blockIdx.x * SLAB_TILE + it * SLAB_BLOCK + threadIdx.x;
         T4 p, v;
         uint32_t f = 0;
-        if (i < n) { p = pos[i]; v = vel[i]; f = slab_flags<R>(P, c, p); }
+        if (i < n) {
+            if (FROM_FLAGS) {
+                f = out.flags[i];
+                if (f & ~(1u << ST_STAY)) { p = pos[i]; v = vel[i]; }
+            } else {
+                p = pos[i]; v = vel[i]; f = slab_flags<R>(P, c, p);
+            }
+        }
         uint32_t rankInWave[ST_COUNT];
         for (int s = 0; s < ST_COUNT; ++s) {
             const unsigned long long m = __ballot((f >> s) & 1u);
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
             if (lane == 0) waveCnt[s][wave] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (INPLACE && i < n) {
+        if (INPLACE && !FROM_FLAGS && i < n) {
             if (!(f & (1u << ST_STAY))) {
                 out.hash[i] = 0xffffffffu;
                 atomicAdd(&out.tileDead[i / SLAB_BLOCK], 1u);

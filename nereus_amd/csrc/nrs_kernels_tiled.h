@@ -24,6 +24,7 @@
 // No MFMA: this is a bandwidth/latency-bound gather, not a dense contraction.
 #pragma once
 #include "nrs_kernels_ref.h"
+#include "nrs_kernels_slab.h"
 
 namespace nrs {
 
@@ -384,6 +385,14 @@ template <typename R> struct FusedOut {
     // changes; both null when the next step sorts from scratch
     const uint32_t *prevHash;
     uint32_t *tileMovers;
+    // slab runs (nrs_kernels_slab.h): classify the particle for the next partition here, where its new position is in
+    // registers — stream flags per slot, per-2048-slot populations of the message/ghost streams, dead slots get the key
+    // 0xffffffff and are counted per 256-slot tile.  slabFlags == nullptr: off.
+    uint8_t *slabFlags;
+    uint32_t *slabBlockCounts;
+    uint32_t slabBlocks;
+    uint32_t *tileDead;
+    SlabCfg slab;
 };
 
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
@@ -401,9 +410,24 @@ NRS_DEV void forces_epilogue(const Params<R> &P, typename Vec4T<R>::type p4, typ
         fo.newVel[i] = mk4<R>(v, v4.w);
         const I3 g = calcGridPos<R>(P, pn);
         const uint32_t h = calcGridHash<R>(P, g.x, g.y, g.z);
-        fo.hash[i] = h;
+        uint32_t key = h;
+        if (fo.slabFlags) {
+            const uint32_t f = slab_flags<R>(P, fo.slab, mk4<R>(pn, p4.w));
+            fo.slabFlags[i] = (uint8_t)f;
+            if (!(f & (1u << ST_STAY))) {
+                key = 0xffffffffu;
+                atomicAdd(&fo.tileDead[i / BLOCK], 1u);
+            } else if (h != fo.prevHash[i]) {
+                atomicAdd(&fo.tileMovers[i / BLOCK], 1u);
+            }
+            if (f & ~(1u << ST_STAY))
+                for (int s = 1; s < ST_COUNT; ++s)
+                    if ((f >> s) & 1u) atomicAdd(&fo.slabBlockCounts[(uint32_t)s * fo.slabBlocks + i / SLAB_TILE], 1u);
+        } else if (fo.tileMovers && h != fo.prevHash[i]) {
+            atomicAdd(&fo.tileMovers[i / BLOCK], 1u);
+        }
+        fo.hash[i] = key;
         fo.index[i] = i;
-        if (fo.tileMovers && h != fo.prevHash[i]) atomicAdd(&fo.tileMovers[i / BLOCK], 1u);
     }
 }
 
@@ -523,6 +547,11 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     fo.hash = fo.index = nullptr;
     fo.prevHash = nullptr;
     fo.tileMovers = nullptr;
+    fo.slabFlags = nullptr;
+    fo.slabBlockCounts = nullptr;
+    fo.slabBlocks = 0;
+    fo.tileDead = nullptr;
+    fo.slab = SlabCfg{0, 0, 0};
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     if (lists) {

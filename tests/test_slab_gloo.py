@@ -81,6 +81,9 @@ def _worker(rank, world, port, steps, use_hip, outdir, skew=0, rebalance_every=0
         drv.exchange()
         moved += drv.last_counts[1] + drv.last_counts[3]
         owned_hist.append(eng.n_owned)
+        if os.environ.get("NEREUS_TEST_TRACE"):
+            print("TRACE rank %d it %d owned %d local %d counts %s cuts %s resort %s" % (rank, it, eng.n_owned, eng.n_local, list(drv.last_counts),
+                                                                          (eng.cell_lo, eng.cell_hi), eng.solver.resort_stats() if use_hip else None), flush=True)
         eng.step(1)
     drv.finish()
     moved += drv.last_counts[1] + drv.last_counts[3]
@@ -153,6 +156,18 @@ def test_slab_hip_engine_coherent_resort(tmp_path, hip_lib):
         # a fall-back (more than 1/8 of the local particles are cell changers + arrivals + halo copies) is legitimate in
         # a slab this narrow, but most steps must have merged
         assert used >= steps - 1 and fallbacks <= used // 3
+
+
+@pytest.mark.gpu
+def test_slab_rebalance_with_fused_classification(tmp_path, hip_lib):
+    """Slabs big enough for the in-place partition, whose classification rides in the force kernel: a re-cut between the
+    step and the partition invalidates that classification (it was made for the old cuts); same bar against the
+    single-domain oracle, counts converge."""
+    moved = _run(2, 9, True, tmp_path, skew=-3, rebalance_every=3, lattice=(48, 28, 26))
+    owned = np.stack(_run.owned)
+    assert abs(int(owned[0, -1]) - int(owned[1, -1])) < abs(int(owned[0, 0]) - int(owned[1, 0])) and moved > 0
+    for used, fallbacks in _run.resort:
+        assert used >= 4
 
 
 def test_message_capacity_rule_covers_the_halo():
