@@ -521,9 +521,11 @@ static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, 
     const CutThresholds thr = make_thresholds<R>(P);
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     HitBuffer hb = {nullptr, nullptr, 0};
+    // occupancy experiment: extra dynamic LDS per workgroup lowers the workgroups per CU
+    static const unsigned pad = getenv("NEREUS_DBG_LDS_PAD") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD")) : 0u;
     if (share) {
         hb = *share;
-        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
+        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true>), g, b, pad, stream, P, G, thr, sPos, dens, pres, hb, n);
     } else {
         hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
     }
