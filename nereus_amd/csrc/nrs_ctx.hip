@@ -155,7 +155,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf bSorted, bHash, bIndex, bHashAlt, bIndexAlt;
     uint32_t *bHashCur = nullptr, *bIndexCur = nullptr;
     // IISPH
-    DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij;
+    DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij, diiSum;
     DevBuf redPartial, redOut;
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
     // coherent re-sort (nrs_kernels_resort.h)
@@ -226,7 +226,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -276,7 +276,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(densAdv.alloc(s)); NRSCHK(densCorr.alloc(s)); NRSCHK(P_l.alloc(s)); NRSCHK(P_l2.alloc(s));
             NRSCHK(aii.alloc(s));
             NRSCHK(velAdv.alloc(v)); NRSCHK(forcesAdv.alloc(v)); NRSCHK(forcesP.alloc(v));
-            NRSCHK(diiF.alloc(v)); NRSCHK(diiB.alloc(v)); NRSCHK(sumDij.alloc(v));
+            NRSCHK(diiF.alloc(v)); NRSCHK(diiB.alloc(v)); NRSCHK(sumDij.alloc(v)); NRSCHK(diiSum.alloc(v));
             DevBuf *z[] = {&densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP, &diiF, &diiB, &sumDij};
             for (DevBuf *b : z) HIPCHK(hipMemsetAsync(b->p, 0, b->bytes, stream));
         }
@@ -530,7 +530,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         I.densAdv = densAdv.as<R>(); I.densCorr = densCorr.as<R>(); I.P_l = P_l.as<R>(); I.P_l_next = P_l2.as<R>();
         I.aii = aii.as<R>();
         I.velAdv = velAdv.as<T4>(); I.forcesAdv = forcesAdv.as<T4>(); I.forcesP = forcesP.as<T4>();
-        I.diiF = diiF.as<T4>(); I.diiB = diiB.as<T4>(); I.sumDij = sumDij.as<T4>();
+        I.diiF = diiF.as<T4>(); I.diiB = diiB.as<T4>(); I.sumDij = sumDij.as<T4>(); I.diiSum = diiSum.as<T4>();
         I.inv = inv.as<uint32_t>();
         return I;
     }

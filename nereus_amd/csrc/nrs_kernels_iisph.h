@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
     }
     I.diiF[i] = mk4<R>(df, (R)0.0);
     I.diiB[i] = mk4<R>(db, (R)0.0);
+    I.diiSum[i] = mk4<R>(df + db, (R)0.0); // the same sum computePressure forms per neighbour (sph_kernel_impl.cuh:1420)
 }
 
 // ---- computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) --------------------------------------------------
@@ -360,10 +361,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
         const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
         const V3<R> dji = dpi * (grad);
         const V3<R> d_ji_pi = dji * p_lj;
-        const V3<R> diifj = xyz<R>(I.diiF[j]);
-        const V3<R> diibj = xyz<R>(I.diiB[j]);
+        const V3<R> diij = xyz<R>(I.diiSum[j]); // = diiF[j] + diiB[j]
         const V3<R> sum_dijj = xyz<R>(I.sumDij[j]);
-        fsum += pm * dot(dijpj - (diifj + diibj) * p_lj - (sum_dijj - d_ji_pi), grad);
+        fsum += pm * dot(dijpj - diij * p_lj - (sum_dijj - d_ji_pi), grad);
     };
     if (hc.over) {
         const I3 gp = calcGridPos<R>(P, pos1);

@@ -337,6 +337,8 @@ template <typename R> struct IisphArrays {
     typedef typename Vec4T<R>::type T4;
     R *densAdv, *densCorr, *P_l, *P_l_next, *aii;
     T4 *velAdv, *forcesAdv, *forcesP, *diiF, *diiB, *sumDij;
+    T4 *diiSum; // diiF + diiB, formed once per step by the list-driven displacement kernel (the pressure kernel's neighbour
+                // term reads only the sum: one 16-byte gather per neighbour and iteration instead of two)
     const uint32_t *inv; // inv[slot] = id of the reference thread that handles the slot
 };
 
