@@ -167,6 +167,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     uint32_t rsSeq = 0;
     hipEvent_t rsEvent = nullptr;
     bool rsPending = false; // movers/stayers of the keys in hashNext have been split; the count is on its way
+    bool splitClearedCells = false; // this step's k_resort_split also reset the cell table
     uint64_t rsSteps = 0, rsFallbacks = 0;
     // slab decomposition
     bool slabOn = false;
@@ -670,8 +671,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_begin(NRS_STAGE_SORT));
         const uint32_t nTiles = nblocks(N);
         NRSCHK(launch_resort_scan(nTiles, false));
+        static const bool allowClear = !(getenv("NEREUS_SPLIT_CLEAR") && atoi(getenv("NEREUS_SPLIT_CLEAR")) == 0);
+        const bool clear = allowClear && (uint64_t)P.numCells > 8ull * n; // the step's cell-table reset rides along (see step())
         hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(), offsets_movers(),
-                           rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                           rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, clear ? cellStart.as<uint32_t>() : (uint32_t *)nullptr);
+        splitClearedCells = clear;
         rsPending = true;
         NRSCHK(ev_end());
         return NRS_OK;
@@ -954,7 +958,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 HIPCHK(hipMemcpyAsync(slabHostTotals + 8, rsScalars.p, 16, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipEventRecord(packEvent, stream));
                 hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
-                                   offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                                   offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
                 HIPCHK(hipGetLastError());
                 rsTilesDirty = false; // the scan resets the counts it reads
                 HIPCHK(hipEventSynchronize(packEvent));
@@ -1010,7 +1014,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                     const uint32_t nTiles = nblocks(N);
                     NRSCHK(launch_resort_scan(nTiles, true));
                     hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
-                                       offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                                       offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
                     HIPCHK(hipGetLastError());
                     rsTilesDirty = false; // the scan resets the counts it reads
                     HIPCHK(hipEventSynchronize(packEvent));
@@ -1105,7 +1109,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             const uint32_t N = (uint32_t)n, nTiles = nblocks(N);
             NRSCHK(launch_resort_scan(nTiles, false));
             hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
-                               offsets_movers(), offsets_movers(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N);
+                               offsets_movers(), offsets_movers(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
             rsPending = true;
             rsCountKnown = true; // everything appended is a mover, and the partition counted the cell changers
             rsKnownCount = packChanged + A.start[5];
@@ -1147,6 +1151,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (n == 0) return NRS_OK;
         for (int s = 0; s < nsteps; ++s) {
             fusedThisStep = false;
+            splitClearedCells = false;
             NRSCHK(stage_prefix(stop));
             if (stop && stop <= NRS_STAGE_REORDER) { midStep = true; break; }
             if (iisph()) { if (nb) NRSCHK(iisph_tail<true>(stop)); else NRSCHK(iisph_tail<false>(stop)); }
@@ -1154,7 +1159,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             HIPCHK(hipGetLastError());
             if (stop) { midStep = true; break; }
             if ((uint64_t)P.numCells > 8ull * n) { // big, mostly empty table: undo only the touched cells
-                hipLaunchKernelGGL(k_clear_cells, dim3(nblocks(n)), dim3(BLOCK), 0, stream, hashCur, cellStart.as<uint32_t>(), (uint32_t)n);
+                if (!splitClearedCells)
+                    hipLaunchKernelGGL(k_clear_cells, dim3(nblocks(n)), dim3(BLOCK), 0, stream, hashCur, cellStart.as<uint32_t>(), (uint32_t)n);
                 cellsClean = true;
             }
             // the integrated sorted arrays become the next step's input (replaces D2H + H2D)

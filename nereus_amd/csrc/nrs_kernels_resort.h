@@ -94,8 +94,11 @@ struct ResortOffsets { const uint32_t *tileOffset, *groupPrefix; };
 template <bool HOLES>
 __global__ __launch_bounds__(BLOCK) void k_resort_split(const uint32_t *__restrict__ prevHash, const uint32_t *__restrict__ nextHash,
                                                         ResortOffsets mov, ResortOffsets dead, uint64_t *__restrict__ movers,
-                                                        uint64_t *__restrict__ stayers, uint32_t n)
+                                                        uint64_t *__restrict__ stayers, uint32_t n, uint32_t *__restrict__ clearCells)
 {
+    // clearCells (cellStart, or null): also undo the cell table of the step that just ended — the work of k_clear_cells
+    // (nrs_kernels_ref.h), folded in here because this kernel reads the step's sorted keys anyway and runs after every
+    // reader of the table
     __shared__ uint32_t waveCount[2][BLOCK / 64];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t i = tile * BLOCK + tid;
@@ -105,7 +108,9 @@ __global__ __launch_bounds__(BLOCK) void k_resort_split(const uint32_t *__restri
     if (live) {
         k = nextHash[i];
         hole = HOLES && k == 0xffffffffu;
-        mover = !hole && k != prevHash[i];
+        const uint32_t prev = prevHash[i];
+        mover = !hole && k != prev;
+        if (clearCells && (i == 0 || prev != prevHash[i - 1])) clearCells[prev] = CELL_EMPTY;
     }
     const uint64_t mask = __ballot(mover), hmask = HOLES ? __ballot(hole) : 0ull;
     const uint32_t lane = tid & 63u, wave = tid >> 6;

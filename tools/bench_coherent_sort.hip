@@ -155,7 +155,7 @@ int main(int argc, char **argv)
         nrs::k_resort_scan_tiles<<<nGroups, nrs::RESORT_GROUP, 0, st>>>(sc, none, dDone, hTotalDev, (uint32_t)(r + 1), nTiles);
         CHK(hipEventRecord(evM, st));
         const nrs::ResortOffsets off = {dTileOffset, dGroupPrefix};
-        nrs::k_resort_split<false><<<nTiles, 256, 0, st>>>(dOld, dNext, off, off, dMov, dStay, n);
+        nrs::k_resort_split<false><<<nTiles, 256, 0, st>>>(dOld, dNext, off, off, dMov, dStay, n, (uint32_t *)nullptr);
         CHK(hipEventRecord(ev[1], st));
         CHK(hipEventSynchronize(evM));
         const uint32_t M = (uint32_t)*hTotal;
