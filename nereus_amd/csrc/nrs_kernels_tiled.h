@@ -55,6 +55,14 @@ struct HitCounts { int nf, nb; bool over; };
 
 template <typename R> struct Sweep {
     typedef typename Vec4T<R>::type T4;
+    // element `idx` of a vec4 array through a 32-bit byte offset from the (wave-uniform) base pointer: lets the
+    // compiler use the scalar-base + 32-bit-vector-offset form of global_load (no 64-bit address arithmetic, two
+    // VGPRs less per address in flight).  Valid because capacities are below 2^27 elements (nrs_create checks).
+    static NRS_DEV T4 at32(const T4 *__restrict__ base, uint32_t idx)
+    {
+        const uint32_t off = idx * (uint32_t)sizeof(T4);
+        return *reinterpret_cast<const T4 *>(reinterpret_cast<const char *>(base) + off);
+    }
 
     // BFILT: cut-off used for boundary candidates: 0 = lenLtIr (explicit test of the density loop); 1 = r2LeH2
     // (the force loop has no explicit test, but every Muller kernel it evaluates returns 0 beyond h);
@@ -91,7 +99,7 @@ template <typename R> struct Sweep {
             for (uint32_t base = 0; base < nT; base += SCAN_BATCH) {
                 T4 c[SCAN_BATCH];
 #pragma unroll
-                for (int u = 0; u < SCAN_BATCH; ++u) c[u] = sPos[a + min(base + (uint32_t)u, nT - 1u)];
+                for (int u = 0; u < SCAN_BATCH; ++u) c[u] = at32(sPos, a + min(base + (uint32_t)u, nT - 1u));
 #pragma unroll
                 for (int u = 0; u < SCAN_BATCH; ++u) {
                     const uint32_t q = base + (uint32_t)u;
