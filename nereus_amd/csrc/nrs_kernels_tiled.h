@@ -46,7 +46,7 @@ struct CutThresholds { float lenLtIr, r2LeH2; };
 #ifndef FORCES_LISTS_MIN_WAVES
 #define FORCES_LISTS_MIN_WAVES 7
 #endif
-constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (8 costs 16 VGPRs, slower)
+constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (6: 79 VGPRs = 6 waves, 0.81 vs 0.71 ms; 8: slower still)
 
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
 // lst[HIT_CAP-1 .. HIT_CAP-nb] (descending slots, ascending visiting order); both lists are ordered by cell
