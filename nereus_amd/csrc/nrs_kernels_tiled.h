@@ -564,8 +564,9 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     fo.slab = SlabCfg{0, 0, 0};
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
+    static const unsigned padF = getenv("NEREUS_DBG_LDS_PAD_F") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD_F")) : 0u; // occupancy experiment
     if (lists) {
-        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
+        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, true>), g, b, padF, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
         else hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
     } else {
         const CutThresholds thr = make_thresholds<R>(P);
