@@ -192,6 +192,50 @@ def test_hash_bit_exact_on_adversarial_positions(hip_lib):
         check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
 
 
+def test_28_bit_grid_sort_paths(hip_lib):
+    """A 2^28-cell grid (as the global grid of a 2-4 rank weak-scaling run): hashes of 28 key bits take the 10-bit
+    radix configurations of both the full sort and the mover sort of the coherent re-sort.  Hash / index / cell tables
+    against the oracle after the first sort, then default path == full-sort path bit for bit over several steps."""
+    p, sc = small_dam_break((36, 34, 32))
+    n = len(sc["pos"])
+    assert n >= 32768
+    p = p.copy()
+    o0 = Oracle(p, solver=SESPH)
+    o0.set_particles(sc["pos"], sc["vel"])
+    o0.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)   # the tank's own grid ...
+    p = o0.params.copy()
+    p["gridSize"][0] = (2048, 512, 256)                         # ... blown up to 2^28 cells around the same origin
+    p["numCells"][0] = 2048 * 512 * 256
+    o = Oracle(p, solver=SESPH, threads=min(16, os.cpu_count() or 1))
+    o.set_particles(sc["pos"], sc["vel"])
+    o.set_boundaries(sc["bi"], sc["vbi"], update_grid=False)
+    solvers = []
+    for flags in (0, capi.FLAG_FULL_SORT):
+        s = capi.Solver(p, n, flags=flags)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=False)
+        solvers.append(s)
+    assert int(solvers[0].params["numCells"][0]) == 1 << 28
+    o.step(3)
+    for s in solvers:
+        s.step(3)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
+        np.testing.assert_array_equal(s.get("index"), o.get("index"))
+    # (the cell table of a finished step has been reset; compare it on a partial step)
+    o1, s1 = make_pair(p, sc["pos"], sc["vel"])
+    o1.step(1, stop=STOP_REORDER); s1.step_partial(capi.STAGE_REORDER)
+    check_cell_tables(s1.get("cellStart"), s1.get("cellEnd"), o1.get("cellStart"), o1.get("cellEnd"))
+    s1.close()
+    for s in solvers:
+        s.step(9)
+    a, b = [s.download() + (s.get("hash"), s.get("index"), s.get("dens")) for s in solvers]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert solvers[0].resort_stats() == (11, 0)
+    for s in solvers:
+        s.close()
+
+
 def test_kernel_path_flags_are_bitwise_equivalent(hip_lib):
     """Fused vs separate force/integrate/hash launches, shared hit lists vs a second scan: same bits."""
     p, sc = small_dam_break((20, 16, 14))
