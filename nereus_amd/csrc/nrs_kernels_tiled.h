@@ -192,16 +192,28 @@ struct HitMerge {
     const uint32_t *base;
     uint32_t stride;
     int nf, nb, kf, kb;
-    NRS_DEV HitMerge(const uint32_t *b, uint32_t st, HitCounts hc) : base(b), stride(st), nf(hc.nf), nb(hc.nb), kf(0), kb(0) {}
+    // the two list heads are fetched one step ahead: when a hit is handed out, the load of its successor is already on
+    // its way and overlaps with the gathers and the arithmetic of the hit (one dependent memory round trip per hit
+    // instead of two when the lists live in global memory)
+    uint32_t headF, headB;
+    NRS_DEV HitMerge(const uint32_t *b, uint32_t st, HitCounts hc) : base(b), stride(st), nf(hc.nf), nb(hc.nb), kf(0), kb(0)
+    {
+        headF = nf > 0 ? base[0] : 0xffffffffu;
+        headB = nb > 0 ? base[(uint32_t)(HIT_CAP - 1) * stride] : 0xffffffffu;
+    }
     NRS_DEV bool next(uint32_t &index, bool &boundary, uint32_t &key)
     {
         if (kf >= nf && kb >= nb) return false;
-        const uint32_t ef = kf < nf ? base[(uint32_t)kf * stride] : 0xffffffffu;
-        const uint32_t eb = kb < nb ? base[(uint32_t)(HIT_CAP - 1 - kb) * stride] : 0xffffffffu;
-        const uint32_t tf = ef >> HIT_TAG_SHIFT, tb = eb >> HIT_TAG_SHIFT;
+        const uint32_t tf = headF >> HIT_TAG_SHIFT, tb = headB >> HIT_TAG_SHIFT;
         boundary = tb < tf; // fluid first inside a cell; the 0xffffffff sentinel has tag 31 > 26
-        const uint32_t e = boundary ? eb : ef;
-        if (boundary) ++kb; else ++kf;
+        const uint32_t e = boundary ? headB : headF;
+        if (boundary) {
+            ++kb;
+            headB = kb < nb ? base[(uint32_t)(HIT_CAP - 1 - kb) * stride] : 0xffffffffu;
+        } else {
+            ++kf;
+            headF = kf < nf ? base[(uint32_t)kf * stride] : 0xffffffffu;
+        }
         index = e & HIT_INDEX;
         key = (e >> HIT_TAG_SHIFT) * 2u + (boundary ? 1u : 0u);
         return true;
