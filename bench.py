@@ -66,7 +66,7 @@ def per_stage_roofline(warm, n, num_cells, production):
 def measured_traffic(stage, n):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC profile (2*FETCH_SIZE + WRITE_SIZE,
     the gfx950 correction of MI355X_MICROARCH.md), scaled by particle count; None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_f_ns10M_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_g_ns10M_hbm_traffic.json")
     try:
         doc = json.load(open(path))
         k = doc["kernels"][KERNEL_OF_STAGE[stage]]
@@ -273,7 +273,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(dominant, n),
-            "traffic_source": "profiles/r01_f_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
+            "traffic_source": "profiles/r01_g_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
                               "scaled by particle count",
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,
