@@ -336,7 +336,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
     R bsum = (R)0.0;
     const R dpi = pm / (dens * dens);
     HitCounts hc = unpack_counts(hb.counts[i]);
-    if (HAS_B) {
+    if (HAS_B && hc.anyB) { // (anyB: the scan saw boundary particles in at least one of the 27 cells; none: nothing to add)
         // boundary part: its own accumulator, so it can run apart from the fluid part.  The loop bounds are the
         // reference's: from the FLUID cell start to the BOUNDARY cell end, over the boundary array.
         const I3 gp = calcGridPos<R>(P, pos1);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R>
         const V3<R> contrib = -pm * pm * (p / (dens * dens) + pj / (densj * densj)) * grad;
         fp = fp + contrib;
     };
-    if (!HAS_B && !hc.over) {
+    if ((!HAS_B || !hc.anyB) && !hc.over) { // no boundary particles in any of the 27 cells: only the fluid list contributes
         hc.nb = 0;
         for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
     } else {

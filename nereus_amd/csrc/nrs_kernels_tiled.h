@@ -51,7 +51,7 @@ constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memo
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
 // lst[HIT_CAP-1 .. HIT_CAP-nb] (descending slots, ascending visiting order); both lists are ordered by cell
 // number, so the process phase restores the reference's order (cell by cell: fluid, then boundary) by merging.
-struct HitCounts { int nf, nb; bool over; };
+struct HitCounts { int nf, nb; bool over; bool anyB; }; // anyB: some of the 27 cells holds boundary particles
 
 template <typename R> struct Sweep {
     typedef typename Vec4T<R>::type T4;
@@ -90,7 +90,7 @@ template <typename R> struct Sweep {
         const float tB = BFILT == 2 ? INFINITY : (BFILT == 1 ? thr.r2LeH2 : thr.lenLtIr);
         const uint32_t tid = threadIdx.x;
         int nf = 0, nb = 0;
-        bool over = false;
+        bool over = false, anyB = false;
 
         // fluid candidates j in [a, b); the cell number advances at j == m1 and j == m2 (starts of the 2nd / 3rd
         // cell of a merged run; CELL_EMPTY when that cell is empty)
@@ -151,6 +151,7 @@ template <typename R> struct Sweep {
                 }
             }
             if (HAS_B) {
+                anyB = anyB || bmask != 0u;
                 // boundary cells of this plane, visited in ascending cell number by the lanes that have any
                 while (bmask) {
                     const int bit = __builtin_ctz(bmask);
@@ -178,7 +179,7 @@ template <typename R> struct Sweep {
             }
         }
         HitCounts hc;
-        hc.nf = nf; hc.nb = nb; hc.over = over;
+        hc.nf = nf; hc.nb = nb; hc.over = over; hc.anyB = anyB;
         return hc;
     }
 };
@@ -349,11 +350,15 @@ NRS_DEV uint32_t xcd_tile(uint32_t b, uint32_t nb)
 // `hb.hits` is set) leaves them in global memory for the force kernel, which then needs no scan and no LDS.
 // hits[k * stride + i] is particle i's k-th list slot (k-major ⇒ coalesced), counts[i] = nf | nb << 8 | over << 16.
 struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; };
-NRS_DEV uint32_t pack_counts(HitCounts hc) { return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u); }
+NRS_DEV uint32_t pack_counts(HitCounts hc)
+{
+    return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u) | (hc.anyB ? 1u << 17 : 0u);
+}
 NRS_DEV HitCounts unpack_counts(uint32_t c)
 {
     HitCounts hc;
     hc.nf = (int)(c & 0xffu); hc.nb = (int)((c >> 8) & 0xffu); hc.over = ((c >> 16) & 1u) != 0u;
+    hc.anyB = ((c >> 17) & 1u) != 0u;
     return hc;
 }
 
