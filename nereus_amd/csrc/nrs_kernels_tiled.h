@@ -10,8 +10,10 @@
 //           squared-distance compare against a precomputed threshold (no sqrt, no divide).  The loop is
 //           organised for memory-level parallelism (measured: the plain cell walk is latency-bound with one
 //           dependent load in flight per thread): 27 table entries per z-plane requested at once, candidate
-//           positions fetched 8 at a time.  Hits are appended to a per-thread list kept in LDS
-//           (lst[k][tid], k-major: conflict-free).
+//           positions fetched SCAN_BATCH (4) at a time.  Hits are appended to a per-thread list kept in LDS
+//           (lst[k][tid], k-major: conflict-free).  Measured on the final kernel: its time grows like 1 / resident
+//           waves (memory-latency-bound), and every attempt to trade registers for more loads in flight lost
+//           (negative results).
 //   process the compacted hits (nearly equal counts across lanes → dense wavefronts) get the expensive
 //           kernel evaluation, in the same order the reference visits them.
 //
@@ -20,6 +22,9 @@
 // into the reference's cell-by-cell order), so the results are
 // bit-identical to the reference-order kernels in nrs_kernels_ref.h — which are also the overflow path
 // for a thread whose hit list would exceed HIT_CAP (correct for any neighbour count).
+//
+// The density kernel publishes its lists to global memory (k-major, hits[k][i]) and the force kernel of the same step
+// walks them (k_forces_lists: no second scan, no LDS), fetching the next list head one hit ahead.
 //
 // No MFMA: this is a bandwidth/latency-bound gather, not a dense contraction.
 #pragma once
