@@ -15,6 +15,7 @@ interface so the protocol can be exercised on CPU with gloo and a checker engine
 the product engine is HipSlabEngine and has no CPU fallback.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -277,7 +278,19 @@ def bench_main(args, lattice, rank, world, local_rank):
     from .params import default_params
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # RCCL (backend "nccl") carries the device buffers directly.  NEREUS_BENCH_BACKEND=gloo — or a failing RCCL
+    # initialisation — falls back to gloo with the messages staged through host memory: slower, but the run still
+    # produces its line instead of dying.
+    backend = os.environ.get("NEREUS_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as e:  # pragma: no cover (needs a broken RCCL to trigger)
+            print("bench: RCCL initialisation failed (%s); falling back to gloo + host staging" % e, file=sys.stderr, flush=True)
+            backend = "gloo"
+    if backend != "nccl":
+        dist.init_process_group(backend="gloo")
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     params = default_params(0)
     t_gen = time.perf_counter()
     p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
@@ -286,7 +299,7 @@ def bench_main(args, lattice, rank, world, local_rank):
     msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos))
     eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank)
     eng.load(pos, vel, bi, vbi)
-    drv = SlabDriver(eng, rank, world)
+    drv = SlabDriver(eng, rank, world, stage_through_host=(backend != "nccl"))
     n_global = info["particles"]
 
     eng.solver.set_profiling(True)
@@ -308,14 +321,14 @@ def bench_main(args, lattice, rank, world, local_rank):
     dist.barrier()
     dt = time.perf_counter() - t0
     dom_ms, dom_launches = eng.solver.stage_ms().get(dominant, (0.0, 0))  # HIP-event pairs of the timed steps, resolved now
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     drv.finish()
-    owned = torch.tensor([eng.n_owned], dtype=torch.int64, device="cuda")
+    owned = torch.tensor([eng.n_owned], dtype=torch.int64, device=dev)
     dist.all_reduce(owned, op=dist.ReduceOp.SUM)
     finite = np.isfinite(eng.owned_state()[0]).all()
-    ok = torch.tensor([1 if finite else 0], dtype=torch.int64, device="cuda")
+    ok = torch.tensor([1 if finite else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(owned.item()) != n_global or int(ok.item()) != 1:
         raise SystemExit("slab run lost particles or went non-finite: %d of %d" % (int(owned.item()), n_global))
@@ -345,8 +358,9 @@ def bench_main(args, lattice, rank, world, local_rank):
         "data": "synthetic",
         "config": {
             "workload": "SESPH dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
-                        "x-slabs with a %d-cell halo exchanged per step by RCCL send/recv"
-                        % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,)),
+                        "x-slabs with a %d-cell halo exchanged per step by %s"
+                        % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,) +
+                           ("RCCL send/recv" if backend == "nccl" else "gloo send/recv staged through host memory (fallback)",)),
             "particles": n_global,
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
