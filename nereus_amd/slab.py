@@ -304,6 +304,8 @@ def bench_main(args, lattice, rank, world, local_rank):
 
     eng.solver.set_profiling(True)
     drv.step(args.warmup)
+    if args.warmup == 0:
+        drv.exchange()  # untimed: creates the communicators (a partition without a step changes no particle)
     eng.synchronize()
     warm = eng.solver.stage_ms()
     dominant = max(warm, key=lambda k: warm[k][0]) if warm else "forces"
