@@ -7,11 +7,15 @@
  *     (file:line cited at each function).  It is written from the reference's behaviour,
  *     not copied from it: one emulated "thread" at a time, sequential, IEEE arithmetic,
  *     no FMA contraction (build with -ffp-contract=off).
- *   * PARITY UNPINNED (formally): the reference ships no tests, golden vectors or fixtures,
- *     and its CUDA path cannot be built here (needs nvcc builtins, cudart, Thrust-CUDA; no
- *     stand-ins were written for them).  The only reference-derived numbers available are the
- *     known answers recorded in SURVEY.md §8c (N and mean density of the default SESPH/IISPH
- *     scenes, IISPH solver iteration count); tests/test_oracle_kat.py checks them.
+ *   * PARITY STATUS: the smoothing kernels and the vector helpers below are PINNED
+ *     against the reference itself — /root/reference/common/kernels_impl.cuh + cuda_helpers/helper_math.h
+ *     compile unmodified with g++ (oracle/Makefile target `ref`, oracle/ref_kernels_driver.cpp) and
+ *     tests/test_oracle_ref_pin.py compares orc_eval with that build bit for bit (>= 10^5 inputs per variant,
+ *     plus the committed fixture tests/golden/ref_kernels_pin.npz).  Everything else — grid hash, cell walk,
+ *     force assembly, integration, the IISPH chain — is PARITY UNPINNED: the reference ships no tests, golden
+ *     vectors or fixtures, and sph/sph_kernel_impl.cuh / sph_cuda.cu / sph.cpp need nvcc builtins, cudart and
+ *     Thrust-CUDA (no stand-ins were written for them).  For those parts the only reference-derived numbers are
+ *     the known answers recorded in SURVEY.md §8c (tests/test_oracle_kat.py).
  *
  * Build (see oracle/Makefile): one .so per reference compile-time configuration
  *   -DDOUBLE_PRECISION={0,1} -DKERNEL_SET={1 Muller,0 Monaghan} -DUSE_SURFACE_TENSION=1
@@ -151,6 +155,34 @@ static inline SVec3 Wmonaghan_grad(SVec3 r, SReal h)                    /* :183-
         gradient = (m_g * scalar * m_invH / dist) * r;
     }
     return gradient;
+}
+/* Akinci cohesion / adhesion kernels (:208-247) — defined by the reference, called nowhere on its path; restated
+ * only so that every function of that file is pinned against oracle/_ref */
+static inline SReal Cakinci(SVec3 r, SReal h, SReal ksurf1, SReal ksurf2)  /* :208-228 */
+{
+    SReal len = length(r);
+    SReal poly = ksurf1;
+    SReal hr = h - len;
+    if (2.0 * len > h && len <= h) {
+        SReal a = (hr * hr * hr) * (len * len * len);
+        return poly * a;
+    } else if (len > 0.0 && 2 * len <= h) {
+        SReal a = 2 * (hr * hr * hr) * (len * len * len);
+        SReal b = ksurf2;
+        return poly * (a - b);
+    }
+    return 0.0;
+}
+static inline SReal Aboundary(SVec3 r, SReal h, SReal bpol)               /* :233-247 */
+{
+    SReal rl = length(r);
+    if (2.0 * rl > h && rl <= h) {
+        SReal a = -((4 * (rl * rl)) / (h));
+        SReal b = (6.0 * rl - 2.0 * h);
+        SReal res = powf(a + b, 1.0 / 4.0);
+        return bpol * res;
+    }
+    return 0.0;
 }
 #if KERNEL_SET == MULLER
 #define W_DENS(r, ir, kp) Wdefault(r, ir, kp)
@@ -1086,6 +1118,39 @@ void orc_recompute_constants(void *params)
     std::memcpy(&p, params, sizeof(p));
     kernelConstants(p, 2);
     std::memcpy(params, &p, sizeof(p));
+}
+
+/* Batch evaluation of the smoothing kernels / vector helpers, same numbering as oracle/ref_kernels_driver.cpp
+ * (which calls the reference's own functions): tests/test_oracle_ref_pin.py compares the two bit for bit. */
+int orc_eval(int which, unsigned n, const SReal *r3, const SReal *s3, SReal h, SReal c0, SReal c1, SReal *out)
+{
+    for (unsigned i = 0; i < n; ++i) {
+        const SVec3 r = mk3(r3[3 * i], r3[3 * i + 1], r3[3 * i + 2]);
+        SVec3 s = mk3(0, 0, 0);
+        if (s3) s = mk3(s3[3 * i], s3[3 * i + 1], s3[3 * i + 2]);
+        SVec3 v = mk3(0, 0, 0);
+        switch (which) {
+        case 0: v.x = Wdefault(r, h, c0); break;
+        case 1: v = Wdefault_grad(r, h, c0); break;
+        case 2: v = Wpressure_grad(r, h, c0); break;
+        case 3: v = Wviscosity_grad(r, h, c0, c1); break;
+        case 4: v.x = Wmonaghan(r, h); break;
+        case 5: v = Wmonaghan_grad(r, h); break;
+        case 6: v.x = Cakinci(r, h, c0, c1); break;
+        case 7: v.x = Aboundary(r, h, c0); break;
+        case 8: v.x = dot(r, s); break;
+        case 9: v.x = length(r); break;
+        case 10: v = r * (float)c0; break;
+        case 11: v = (float)c0 * r; break;
+        case 12: v = r / (float)c0; break;
+        case 13: v = mk3(mk4(r.x, r.y, r.z, (SReal)7)); break;
+        case 14: v = r + s; break;
+        case 15: v = r - s; break;
+        default: return -1;
+        }
+        out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    }
+    return 0;
 }
 
 void *orc_create(const void *params)
