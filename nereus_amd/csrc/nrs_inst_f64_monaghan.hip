@@ -1,0 +1,5 @@
+// the double / KS_MONAGHAN contexts (see nrs_ctx_impl.h)
+#include "nrs_ctx_impl.h"
+namespace nrs {
+template CtxBase *make_ctx2<double, KS_MONAGHAN>(bool);
+}

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
 
 // Undo of the cell table after a step: reset cellStart of exactly the cells the step filled (replaces the
 // reference's per-step cudaMemset of 4*numCells bytes, sph_cuda.cu:318, whose cost grows with the EMPTY volume)
-__global__ __launch_bounds__(BLOCK) void k_clear_cells(const uint32_t *__restrict__ hash, uint32_t *__restrict__ cellStart,
+static __global__ __launch_bounds__(BLOCK) void k_clear_cells(const uint32_t *__restrict__ hash, uint32_t *__restrict__ cellStart,
                                                        uint32_t n)
 {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void k_sum_partial(const R *__restrict__ a, 
         partial[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_sum_final(const double *__restrict__ partial, double *__restrict__ out,
+static __global__ __launch_bounds__(BLOCK) void k_sum_final(const double *__restrict__ partial, double *__restrict__ out,
                                                      uint32_t nblocks)
 {
     __shared__ double sm[BLOCK / 64];

@@ -32,7 +32,7 @@ constexpr uint64_t RESORT_MAX_MOVER_DIV = 8;     // more than N/8 movers: full r
 struct ResortScan { // one scanned array: counts in, offsets (local to the group) + group totals/prefixes out
     uint32_t *tile, *tileOffset, *groupTotal, *groupPrefix, *total;
 };
-__global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(ResortScan a, ResortScan b, uint32_t *__restrict__ done,
+static __global__ __launch_bounds__(RESORT_GROUP) void k_resort_scan_tiles(ResortScan a, ResortScan b, uint32_t *__restrict__ done,
                                                                      volatile uint64_t *hostTotal, uint32_t seq, uint32_t nTiles)
 {
     // a = movers (always), b = dead slots (slab runs that leave holes; b.tile == nullptr otherwise).  The total of `a`
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_holes_compact(const uint32_t *__restr
     outVel[d] = vel[i];
 }
 // per-tile count of dead slots (input of the scan that k_holes_compact needs)
-__global__ __launch_bounds__(BLOCK) void k_holes_count(const uint32_t *__restrict__ keys, uint32_t *__restrict__ tileDead, uint32_t n)
+static __global__ __launch_bounds__(BLOCK) void k_holes_count(const uint32_t *__restrict__ keys, uint32_t *__restrict__ tileDead, uint32_t n)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t m = __ballot(i < n && keys[i] == 0xffffffffu);

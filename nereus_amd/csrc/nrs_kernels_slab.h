@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_count(Params<R> P, SlabCfg 
 }
 
 // pass 2: exclusive scan of the block counts, one workgroup per stream; totals[s] = stream population
-__global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scan(uint32_t *__restrict__ blockCounts, uint32_t nBlocks,
+static __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scan(uint32_t *__restrict__ blockCounts, uint32_t nBlocks,
                                                           uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t waveSum[SLAB_BLOCK / 64];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
     }
 }
 
-__global__ void k_slab_headers(const uint32_t *__restrict__ totals, unsigned char *sendL, unsigned char *sendR)
+static __global__ void k_slab_headers(const uint32_t *__restrict__ totals, unsigned char *sendL, unsigned char *sendR)
 {
     if (threadIdx.x == 0 && sendL) {
         uint32_t *h = (uint32_t *)sendL;
