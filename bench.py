@@ -28,23 +28,43 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured-achievable)
+TRAFFIC_PROFILE = "r01_g_ns10M_hbm_traffic.json"  # committed rocprofv3 PMC summary the `traffic` field is read from
 
-# algorithmic bytes per particle per launch of each stage (V=16 B vec4, S=4 B scalar, U=4 B)
-STAGE_BYTES_F32 = {"hash": 16 + 8, "reorder": 8 + 4 * 16 + 2 * 4, "density": 16 + 2 * 4, "forces": 3 * 16 + 2 * 4,
-                   "integrate": 5 * 16}
-# IISPH stages: density V+S, displacement 6V+S, advection 5V+5S, per solver iteration sumDij 2V+2S +
-# pressure 4V+7S + reduce S (= 136 B, times L iterations per step), pressure force 2V+2S, integrate 5V
-IISPH_STAGE_BYTES_F32 = {"i_density": 20, "i_displacement": 100, "i_advection": 100, "i_solve": 136, "i_pforce": 40,
-                         "i_integrate": 80}
-# a full step on the production kernels runs forces + integrate + next-step hash as ONE launch: its algorithmic
-# bytes are the sum of the three reference stages it implements
-FUSED_FORCES_BYTES_F32 = STAGE_BYTES_F32["forces"] + STAGE_BYTES_F32["integrate"] + STAGE_BYTES_F32["hash"]
+
+
+def stage_bytes(real_bytes=4):
+    """algorithmic bytes per particle per launch of each stage (V = vec4, S = scalar, U = 4 B):
+    fp32 V=16 S=4, fp64 V=32 S=8"""
+    V, S, U = 4 * real_bytes, real_bytes, 4
+    return {"hash": V + 2 * U, "reorder": 2 * U + 4 * V + 2 * S, "density": V + 2 * S, "forces": 3 * V + 2 * S,
+            "integrate": 5 * V}
+
+
+def iisph_stage_bytes(real_bytes=4):
+    """IISPH stages: density V+S, displacement 6V+S, advection 5V+5S, per solver iteration sumDij 2V+2S +
+    pressure 4V+7S + reduce S (times L iterations per step), pressure force 2V+2S, integrate 5V"""
+    V, S = 4 * real_bytes, real_bytes
+    return {"i_density": V + S, "i_displacement": 6 * V + S, "i_advection": 5 * V + 5 * S, "i_solve": 6 * V + 10 * S,
+            "i_pforce": 2 * V + 2 * S, "i_integrate": 5 * V}
+
+
+def fused_forces_bytes(real_bytes=4):
+    """a full step on the production kernels runs forces + integrate + next-step hash as ONE launch: its algorithmic
+    bytes are the sum of the three reference stages it implements"""
+    b = stage_bytes(real_bytes)
+    return b["forces"] + b["integrate"] + b["hash"]
+
+
+STAGE_BYTES_F32 = stage_bytes(4)
+IISPH_STAGE_BYTES_F32 = iisph_stage_bytes(4)
+FUSED_FORCES_BYTES_F32 = fused_forces_bytes(4)
 KERNEL_OF_STAGE = {"forces": "k_forces_lists", "density": "k_density_tiled", "reorder": "k_reorder_merged", "hash": "k_hash",
                    "integrate": "k_integrate", "sort": "k_resort_split"}
 
 
-def per_stage_roofline(warm, n, num_cells, production):
+def per_stage_roofline(warm, n, num_cells, production, real_bytes=4):
     out = {}
+    sb = stage_bytes(real_bytes)
     fused = production and "integrate" not in warm
     bits = max(1, int(np.ceil(np.log2(max(2, num_cells)))))
     for name, (ms, launches) in warm.items():
@@ -53,9 +73,9 @@ def per_stage_roofline(warm, n, num_cells, production):
         if name == "sort":
             bpp = 16 * ((bits + 7) // 8) + 4
         elif name == "forces" and fused:
-            bpp = FUSED_FORCES_BYTES_F32
+            bpp = fused_forces_bytes(real_bytes)
         else:
-            bpp = STAGE_BYTES_F32.get(name)
+            bpp = sb.get(name)
         if bpp is None:
             continue
         gbs = bpp * n / (ms / launches * 1e-3) / 1e9
@@ -66,7 +86,7 @@ def per_stage_roofline(warm, n, num_cells, production):
 def measured_traffic(stage, n):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC profile (2*FETCH_SIZE + WRITE_SIZE,
     the gfx950 correction of MI355X_MICROARCH.md), scaled by particle count; None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_g_ns10M_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
         doc = json.load(open(path))
         k = doc["kernels"][KERNEL_OF_STAGE[stage]]
@@ -135,6 +155,48 @@ def cpu_baseline(seconds_target=15.0):
     }
 
 
+def developed_record(s, capi, n, skip, steps, steps_before, bpp, real_bytes, torch):
+    """The same step once the dam has broken ("mean of >= 100 steps after warm-up"): `skip` untimed steps
+    after the contract's timed region, then `steps` timed ones with every stage on HIP events.  The resting column of
+    the first steps is the cheapest regime of the whole run (exactly 6 neighbours per particle, no movers)."""
+    s.set_profiling(False)
+    s.step(skip)
+    s.synchronize()
+    st0, fb0 = s.resort_stats()
+    s.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.step(steps)
+    s.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stages = {k: v[0] / max(1, v[1]) for k, v in s.stage_ms().items()}
+    st1, fb1 = s.resort_stats()
+    rec = {
+        "first_step": steps_before + skip,
+        "steps": steps,
+        "ms_per_step": 1e3 * dt / steps,
+        "value": n * steps / dt,
+        "whole_step_frac": bpp * n * steps / dt / 1e9 / HBM_PEAK_GBS,
+        "stage_ms": stages,
+        "coherent_resort_steps": st1 - st0,
+        "fell_back_to_full_sort": fb1 - fb0,
+    }
+    try:
+        rec["mover_fraction_last_step"] = s.get_stat(capi.STAT_MOVERS) / n
+        rec["hit_list_overflow_fraction"] = s.get_stat(capi.STAT_HIT_OVERFLOW) / n
+        rec["neighbours_mean"] = s.get_stat(capi.STAT_HIT_MEAN)
+        rec["neighbours_max"] = s.get_stat(capi.STAT_HIT_MAX)
+    except capi.NereusError as e:  # (reference-order kernels keep no hit lists)
+        rec["stats_unavailable"] = str(e)
+    dom = max(stages, key=stages.get) if stages else None
+    if dom:
+        b = fused_forces_bytes(real_bytes) if (dom == "forces" and "integrate" not in stages) else stage_bytes(real_bytes).get(dom, 0)
+        rec["dominant"] = {"kernel": dom, "kernel_avg_ms": stages[dom],
+                           "frac": b * n / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if stages[dom] > 0 else 0.0}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +208,14 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = every rank gets a block of --config size (default, the driver contract); strong = the "
                          "--config lattice is split across the ranks in x (e.g. --config C4 --gpus 8: 16M particles, 2M per GPU)")
+    ap.add_argument("--precision", type=int, default=32, choices=[32, 64],
+                    help="SReal: 32 (default, the reference's shipped build) or 64 (DOUBLE_PRECISION=1, config 5)")
+    ap.add_argument("--kernel-set", default="muller", choices=["muller", "monaghan"],
+                    help="KERNEL_SET: muller (default) or monaghan (config 5)")
+    ap.add_argument("--developed", type=int, default=None, metavar="SKIP",
+                    help="N=1 SESPH: after the timed region run SKIP more untimed steps (default 600; 0 = off) and time "
+                         "--developed-steps more: the `developed` sub-record of the JSON line (the dam has broken by then)")
+    ap.add_argument("--developed-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
     ap.add_argument("--full-sort", action="store_true", help="sort all pairs from scratch every step (NRS_FLAG_FULL_SORT)")
@@ -191,14 +261,17 @@ def main():
     from nereus_amd.params import default_params
 
     iisph = args.solver == "iisph"
-    p = default_params(1 if iisph else 0)  # constructor defaults (sph/sph.cpp:29-93, iisph/iisph.cpp:28-87)
+    double = args.precision == 64
+    real, real_bytes = (np.float64, 8) if double else (np.float32, 4)
+    kset = capi.MULLER if args.kernel_set == "muller" else capi.MONAGHAN
+    p = default_params(1 if iisph else 0, double)  # constructor defaults (sph/sph.cpp:29-93, iisph/iisph.cpp:28-87)
     t_gen = time.perf_counter()
-    sc = scene.dam_break(lattice, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    sc = scene.dam_break(lattice, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]), real=real)
     t_gen = time.perf_counter() - t_gen
     n = len(sc["pos"])
     stream = torch.cuda.current_stream().cuda_stream
-    s = capi.Solver(p, n, solver=capi.IISPH if iisph else capi.SESPH, device=local_rank, stream=stream,
-                    reference_order=args.reference_order, flags=capi.FLAG_FULL_SORT if args.full_sort else 0)
+    s = capi.Solver(p, n, solver=capi.IISPH if iisph else capi.SESPH, double=double, kernel_set=kset, device=local_rank,
+                    stream=stream, reference_order=args.reference_order, flags=capi.FLAG_FULL_SORT if args.full_sort else 0)
     s.set_particles(sc["pos"], sc["vel"])
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     P = s.params
@@ -229,14 +302,17 @@ def main():
 
     ms_per_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
-    bpp, passes = sesph_bytes_per_particle_step(num_cells)
-    if iisph:  # 448 + 16 P + 136 L bytes per particle-step, L = solver iterations of the last step
-        bpp = 448 + 16 * passes + 136 * s.last_iterations
+    bpp, passes = sesph_bytes_per_particle_step(num_cells, real_bytes)
+    isb = iisph_stage_bytes(real_bytes)
+    if iisph:  # 448 + 16 P + 136 L bytes per particle-step (fp32), L = solver iterations of the last step
+        sb = stage_bytes(real_bytes)
+        bpp = (sb["hash"] + 4 + sb["reorder"] + isb["i_density"] + isb["i_displacement"] + isb["i_advection"] + isb["i_pforce"]
+               + isb["i_integrate"] + 16 * passes + isb["i_solve"] * s.last_iterations)
     fused = dominant == "forces" and not args.reference_order and "integrate" not in warm
-    if dominant in IISPH_STAGE_BYTES_F32:
-        dom_bpp = IISPH_STAGE_BYTES_F32[dominant] * (s.last_iterations if dominant == "i_solve" else 1)
+    if dominant in isb:
+        dom_bpp = isb[dominant] * (s.last_iterations if dominant == "i_solve" else 1)
     else:
-        dom_bpp = FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)
+        dom_bpp = fused_forces_bytes(real_bytes) if fused else stage_bytes(real_bytes).get(dominant, 0)
     dom_bytes = dom_bpp * n
     dom_avg_ms = dom_ms / max(1, dom_launches)
     achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
@@ -251,11 +327,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f64" if double else "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%s dam-break %dx%dx%d = %d particles (+%d tank boundary particles), fp32, Muller kernels, "
+            "workload": "%s dam-break %dx%dx%d = %d particles (+%d tank boundary particles), %s, %s kernels, "
                         "grid %dx%dx%d" % (("IISPH" if iisph else "SESPH",) + lattice + (n, len(sc["bi"]))
+                                           + ("fp64 (DOUBLE_PRECISION=1)" if double else "fp32",
+                                              "Muller" if kset == capi.MULLER else "Monaghan (KERNEL_SET=0)")
                                            + tuple(int(v) for v in P["gridSize"][0])),
             "particles": n,
             "boundary_particles": int(len(sc["bi"])),
@@ -273,8 +351,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(dominant, n),
-            "traffic_source": "profiles/r01_g_ns10M_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
-                              "scaled by particle count",
+            "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), "
+                              "scaled by particle count" % TRAFFIC_PROFILE,
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes,
@@ -288,11 +366,14 @@ def main():
         "stage_ms_warmup_avg": {k: v[0] / max(1, v[1]) for k, v in warm.items()},
         # every stage against the same roofline (algorithmic bytes of the reference stage(s) it implements / its mean
         # HIP-event time in the warm-up)
-        "per_stage_roofline": per_stage_roofline(warm, n, num_cells, not args.reference_order),
+        "per_stage_roofline": per_stage_roofline(warm, n, num_cells, not args.reference_order, real_bytes),
         "scene_build_s": t_gen,
     }
     if iisph:
         out["config"]["solver_iterations_last_step"] = s.last_iterations
+    skip = args.developed if args.developed is not None else (600 if (not iisph and not args.reference_order) else 0)
+    if skip > 0 and not iisph:
+        out["developed"] = developed_record(s, capi, n, skip, args.developed_steps, args.warmup + args.steps, bpp, real_bytes, torch)
     if not args.no_cpu_baseline and not iisph:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

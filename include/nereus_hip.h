@@ -253,9 +253,18 @@ int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32
 
 /* Coherent re-sort statistics since nrs_create: steps whose (hash, index) pairs were produced by sorting only the
  * particles that changed cell and merging them into the rest, and how many of those fell back to the full radix sort
- * because more than 1/8 of the particles had moved.  (Steps after an upload or a grid change and partial steps
- * always use the full sort and are not counted.) */
+ * because more than half of the particles had moved (the measured break-even).  (Steps after an upload
+ * or a grid change and partial steps always use the full sort and are not counted.) */
 int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks);
+
+/* Diagnostics of the last completed step, as doubles (they synchronize the stream):
+ *   NRS_STAT_MOVERS         particles that changed grid cell (the mover count of the last coherent re-sort; -1 if the
+ *                           last step sorted from scratch without counting)
+ *   NRS_STAT_HIT_OVERFLOW   particles whose neighbour hit list overflowed (they take the reference-order cell walk)
+ *   NRS_STAT_HIT_MEAN/_MAX  neighbours (fluid + boundary hits) per particle kept in the hit lists
+ * The HIT_* values need the shared hit lists of the production kernels (NRS_E_STATE otherwise). */
+enum { NRS_STAT_MOVERS = 0, NRS_STAT_HIT_OVERFLOW = 1, NRS_STAT_HIT_MEAN = 2, NRS_STAT_HIT_MAX = 3 };
+int nrs_get_stat(nrs_ctx *ctx, int which, double *out);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);

@@ -21,6 +21,7 @@ FLAG_NO_FUSION = 4
 FLAG_NO_SHARED_LISTS = 8
 FLAG_FULL_SORT = 16
 E_NOTREADY = -6
+STAT_MOVERS, STAT_HIT_OVERFLOW, STAT_HIT_MEAN, STAT_HIT_MAX = 0, 1, 2, 3
 
 # NRS_STAGE_*
 STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
@@ -48,6 +49,7 @@ EXPORTS = [
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
     "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats", "nrs_snapshot_begin", "nrs_snapshot_wait",
+    "nrs_get_stat",
 ]
 
 
@@ -111,6 +113,7 @@ def load_library(path=None):
     lib.nrs_slab_message_bytes.restype = u64
     lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.nrs_resort_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.nrs_get_stat.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.nrs_snapshot_begin.argtypes = [vp, i32]
     lib.nrs_snapshot_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     _lib = lib
@@ -300,6 +303,11 @@ class Solver:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self.lib.nrs_resort_stats(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def get_stat(self, which):
+        v = C.c_double()
+        self._chk(self.lib.nrs_get_stat(self.h, int(which), C.byref(v)))
+        return v.value
 
     @property
     def n_owned(self):

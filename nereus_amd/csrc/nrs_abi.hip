@@ -210,6 +210,12 @@ int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks)
     ctx->impl->resort_stats(steps, fallbacks);
     return NRS_OK;
 }
+int nrs_get_stat(nrs_ctx *ctx, int which, double *out)
+{
+    CTX_GUARD(ctx);
+    if (!out) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->get_stat(which, out);
+}
 uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision) { return 16 + capacity * 2 * (precision == 64 ? 32 : 16); }
 
 int nrs_max_density(nrs_ctx *ctx, double *out)

@@ -92,6 +92,9 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool rsPending = false; // movers/stayers of the keys in hashNext have been split; the count is on its way
     bool splitClearedCells = false; // this step's k_resort_split also reset the cell table
     uint64_t rsSteps = 0, rsFallbacks = 0;
+    double lastMovers = -1.0; // mover count of the last coherent re-sort
+    uint32_t rsMaxPct = getenv("NEREUS_RESORT_MAX_PCT") ? (uint32_t)atoi(getenv("NEREUS_RESORT_MAX_PCT")) : RESORT_MAX_MOVER_PCT;
+    bool few_movers(uint64_t M, uint64_t N) const { return M * 100ull <= N * (uint64_t)rsMaxPct; }
     // slab decomposition
     bool slabOn = false;
     SlabCfg slab = {INT_MIN / 2, INT_MAX / 2, 2};
@@ -224,7 +227,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         // coherent re-sort: SESPH steps on the production kernels re-use the previous step's order
         if (!(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_FUSION | NRS_FLAG_FULL_SORT)) && cap >= RESORT_MIN_PARTICLES) {
             const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
-            const size_t mcap = cap / RESORT_MAX_MOVER_DIV + 1;
+            const size_t mcap = cap; // any share of the particles may be movers (see rsMaxPct)
             NRSCHK(rsMovers.alloc(8 * cap)); NRSCHK(rsMoversAlt.alloc(8 * mcap)); NRSCHK(rsStayers.alloc(8 * cap)); NRSCHK(rsMerged.alloc(8 * cap));
             NRSCHK(rsTileMovers.alloc(4 * nTiles)); NRSCHK(rsTileOffset.alloc(4 * nTiles));
             NRSCHK(rsGroupTotal.alloc(4 * nGroups)); NRSCHK(rsGroupPrefix.alloc(4 * nGroups)); NRSCHK(rsScalars.alloc(16));
@@ -265,12 +268,20 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const bool sameGrid = std::memcmp(P.gridSize, q.gridSize, sizeof(P.gridSize)) == 0 && q.numCells == P.numCells &&
                               std::memcmp(P.worldOrigin, q.worldOrigin, sizeof(P.worldOrigin)) == 0 &&
                               std::memcmp(P.cellSize, q.cellSize, sizeof(P.cellSize)) == 0;
-        if (!sameGrid) { hashReady = false; slotOrderValid = false; }
+        if (!sameGrid) NRSCHK(invalidate_grid_state());
         P = q;
-        if (regrid) {
-            NRSCHK(alloc_cells());
-            if (nb) NRSCHK(rebuild_boundary_tables());
-        }
+        if (regrid) NRSCHK(alloc_cells());
+        if (!sameGrid && nb) NRSCHK(rebuild_boundary_tables()); // the boundary hashes / cell table depend on origin, cell size and extents
+        return NRS_OK;
+    }
+    // The grid (origin, cell size or extents) is about to change: every key computed for the old grid is void — the
+    // keys the fused kernel prepared for the next step, the split of the coherent re-sort, the slot order, a slab
+    // classification — and the cell table has to be reset in full (k_clear_cells undoes only cells of the OLD keys).
+    int invalidate_grid_state()
+    {
+        NRSCHK(compact_holes());
+        hashReady = false; rsPending = false; rsCountKnown = false; slotOrderValid = false; classifiedValid = false;
+        packedHashValid = false; cellsClean = false;
         return NRS_OK;
     }
     int get_params(void *params) override
@@ -360,6 +371,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         hostVbi.assign((const R *)vbi, (const R *)vbi + nb);
         if (!nb) return NRS_OK;
         if (update_grid) {
+            NRSCHK(invalidate_grid_state());
             // BBMin/BBMax (sph_cuda.cu:461-505) + SPH::updateGrid (sph.cpp:313-337)
             R mn[3] = {hostBi[0].x, hostBi[0].y, hostBi[0].z}, mx[3] = {hostBi[0].x, hostBi[0].y, hostBi[0].z};
             for (uint64_t i = 1; i < nb; ++i) {
@@ -466,7 +478,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const dim3 g(nblocks(N)), b(BLOCK);
         if (holesPending) { // in-place slab partition: only the merge path can consume arrays with holes
             const bool canMerge = hashReady && rsPending && rsCountKnown && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT &&
-                                  (uint64_t)rsKnownCount * RESORT_MAX_MOVER_DIV <= n;
+                                  few_movers(rsKnownCount, n);
             if (!canMerge) {
                 if (hashReady && rsPending && rsCountKnown) { ++rsSteps; ++rsFallbacks; }
                 NRSCHK(compact_holes()); // also drops the prepared keys: hash and sort from scratch below
@@ -499,7 +511,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             uint32_t M = rsKnownCount;
             if (!countKnown) NRSCHK(wait_mover_count(&M));
             ++rsSteps;
-            if ((uint64_t)M * RESORT_MAX_MOVER_DIV <= (uint64_t)N) {
+            lastMovers = (double)M;
+            if (few_movers(M, N)) {
                 if (M == 0) {
                     merged = rsStayers.as<uint64_t>();
                 } else {
@@ -516,6 +529,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             }
         }
         if (!merged) {
+            if (!resort) lastMovers = -1.0;
             rocprim::double_buffer<uint32_t> k(kIn, kAlt);
             rocprim::double_buffer<uint32_t> v(vIn, vAlt);
             size_t tmp = sortTmp.bytes;
@@ -1067,6 +1081,21 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         if (steps) *steps = rsSteps;
         if (fallbacks) *fallbacks = rsFallbacks;
+    }
+    int get_stat(int which, double *out) override
+    {
+        if (which == NRS_STAT_MOVERS) { *out = lastMovers; return NRS_OK; }
+        if (which != NRS_STAT_HIT_OVERFLOW && which != NRS_STAT_HIT_MEAN && which != NRS_STAT_HIT_MAX) return fail(NRS_E_INVALID, "unknown statistic");
+        if (!hitCounts.p || !n || midStep) return fail(NRS_E_STATE, "no shared hit lists (reference-order kernels, or no step yet)");
+        const uint32_t N = (uint32_t)n;
+        HIPCHK(hipMemsetAsync(redPartial.p, 0, 3 * sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(k_hit_stats, dim3(std::min<uint32_t>(1024u, nblocks(N))), dim3(BLOCK), 0, stream, hitCounts.as<uint32_t>(),
+                           (unsigned long long *)redPartial.p, N);
+        unsigned long long h[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h, redPartial.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        *out = which == NRS_STAT_HIT_OVERFLOW ? (double)h[0] : (which == NRS_STAT_HIT_MEAN ? (double)h[1] / (double)N : (double)h[2]);
+        return NRS_OK;
     }
     int step(int nsteps, int stop) override
     {

@@ -16,7 +16,8 @@
 //   rocprim::merge                 stayers + movers → merged[]
 //   k_reorder_merged               cell ranges + gather from merged[], also leaves plain hash[] / index[] arrays
 // The host needs the mover count to size the last two calls: it is read after the split has been queued, so the
-// copy overlaps the split and the cell-table reset; above N/8 movers the step falls back to the full radix sort.
+// copy overlaps the split and the cell-table reset; above RESORT_MAX_MOVER_PCT % movers the step falls back to the full
+// radix sort.
 #pragma once
 #include "nrs_kernels_ref.h"
 
@@ -24,7 +25,8 @@ namespace nrs {
 
 constexpr int RESORT_GROUP = 1024;              // tiles per scan workgroup
 constexpr uint64_t RESORT_MIN_PARTICLES = 32768; // below this the full sort is launch-bound either way
-constexpr uint64_t RESORT_MAX_MOVER_DIV = 8;     // more than N/8 movers: full radix sort
+constexpr uint32_t RESORT_MAX_MOVER_PCT = 50;    // more movers than this share of N: full radix sort (measured break-even,
+                                                 // DESIGN.md §4; NEREUS_RESORT_MAX_PCT overrides it for experiments)
 
 // Exclusive scan of the per-tile mover counts, two levels: every workgroup scans RESORT_GROUP counts (coalesced; the
 // counts are reset to 0 for the next step's atomics) and the last one to finish scans the group totals.

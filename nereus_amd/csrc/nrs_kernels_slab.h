@@ -186,7 +186,9 @@ __global__ __launch_bounds__(SLAB_BLOCK) void k_slab_scatter(Params<R> P, SlabCf
                     }
                     break;
                 }
-                case ST_GHOST: out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; break;
+                case ST_GHOST: // (the ghost arrays hold out.cap particles; the host reports the overflow from the totals)
+                    if (idx < out.cap) { out.ghostPos[idx] = tagged; out.ghostVel[idx] = v; }
+                    break;
                 case ST_MIG_L:
                     if (out.sendL && idx < out.cap) { msg_pos<R>(out.sendL)[idx] = p; msg_vel<R>(out.sendL, out.cap)[idx] = v; }
                     break;

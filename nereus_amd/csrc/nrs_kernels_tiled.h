@@ -367,6 +367,31 @@ NRS_DEV HitCounts unpack_counts(uint32_t c)
     return hc;
 }
 
+// diagnostics over the published hit counts: out[0] = particles whose list overflowed, out[1] = sum of hits (lists that
+// did not overflow), out[2] = longest list
+static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__restrict__ counts, unsigned long long *__restrict__ out, uint32_t n)
+{
+    unsigned long long over = 0, sum = 0, mx = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const HitCounts hc = unpack_counts(counts[i]);
+        if (hc.over) { ++over; continue; }
+        const unsigned long long k = (unsigned long long)(hc.nf + hc.nb);
+        sum += k;
+        mx = k > mx ? k : mx;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        over += __shfl_down(over, d);
+        sum += __shfl_down(sum, d);
+        const unsigned long long o = __shfl_down(mx, d);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&out[0], over);
+        atomicAdd(&out[1], sum);
+        atomicMax(&out[2], mx);
+    }
+}
+
 // ---- density + Tait pressure (computeDensityPressure, sph_kernel_impl.cuh:365-433) -----------------------
 // SHARE: build the lists with the force loop's (wider) boundary cut-off and publish them for the force kernel.
 // WIDE (IISPH, Muller kernels): the published lists keep self and every candidate up to r2LeH2, for the six other

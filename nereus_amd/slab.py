@@ -88,8 +88,12 @@ class HipSlabEngine:
         self.torch = torch
         self.device = torch.device("cuda", device_index)
         self.msg_capacity = int(msg_capacity)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.solver = capi.Solver(params, capacity, solver=capi.SESPH, device=device_index, stream=stream)
+        # The solver and the exchange must run on ONE real stream: torch's default stream is the NULL stream, which
+        # nrs_create takes as "make your own non-blocking stream" — and a req.wait() on torch's stream would then order
+        # nothing against the solver's (the receive could still be in flight when nrs_slab_unpack reads the headers).
+        self.stream = torch.cuda.Stream(device=self.device)
+        assert self.stream.cuda_stream != 0
+        self.solver = capi.Solver(params, capacity, solver=capi.SESPH, device=device_index, stream=self.stream.cuda_stream)
         self.cell_lo, self.cell_hi, self.halo = cell_lo, cell_hi, halo
         self.msg_bytes = self.solver.message_bytes(self.msg_capacity)
         self._configured = False
@@ -160,6 +164,14 @@ class SlabDriver:
         self.last_counts = None
 
     def exchange(self):
+        """pack -> one send/recv per neighbour -> unpack, all ordered on the engine's stream (when it has one)."""
+        stream = getattr(self.engine, "stream", None)
+        if stream is None:
+            return self._exchange()
+        with self.torch.cuda.stream(stream):
+            return self._exchange()
+
+    def _exchange(self):
         dist, eng = self.dist, self.engine
         self.last_counts = eng.pack(self.send_l, self.send_r)
         ops, host = [], {}
@@ -278,17 +290,15 @@ def bench_main(args, lattice, rank, world, local_rank):
     from .params import default_params
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # RCCL (backend "nccl") carries the device buffers directly.  NEREUS_BENCH_BACKEND=gloo — or a failing RCCL
-    # initialisation — falls back to gloo with the messages staged through host memory: slower, but the run still
-    # produces its line instead of dying.
+    # RCCL (backend "nccl") carries the device buffers directly.  NEREUS_BENCH_BACKEND=gloo (asked for explicitly) stages
+    # the messages through host memory instead; a failing RCCL initialisation is an ERROR, never a silent downgrade — a
+    # host-staged number must not be mistaken for an xGMI scaling result.  The line carries "backend" either way.
     backend = os.environ.get("NEREUS_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("NEREUS_BENCH_BACKEND must be nccl or gloo")
     if backend == "nccl":
-        try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        except Exception as e:  # pragma: no cover (needs a broken RCCL to trigger)
-            print("bench: RCCL initialisation failed (%s); falling back to gloo + host staging" % e, file=sys.stderr, flush=True)
-            backend = "gloo"
-    if backend != "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
         dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     params = default_params(0)
@@ -358,11 +368,12 @@ def bench_main(args, lattice, rank, world, local_rank):
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "backend": "rccl" if backend == "nccl" else "gloo+host-staging",
         "config": {
             "workload": "SESPH dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
                         "x-slabs with a %d-cell halo exchanged per step by %s"
                         % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,) +
-                           ("RCCL send/recv" if backend == "nccl" else "gloo send/recv staged through host memory (fallback)",)),
+                           ("RCCL send/recv" if backend == "nccl" else "gloo send/recv staged through host memory (NEREUS_BENCH_BACKEND=gloo)",)),
             "particles": n_global,
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,

@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     const double frac = argc > 2 ? atof(argv[2]) : 0.03;
     const uint32_t bits = 27, gx = 1024, gy = 512;
     const int variant = argc > 3 ? atoi(argv[3]) : 0;
-    const uint32_t mcap = n / 8;
+    const uint32_t mcap = n; // any share of movers
     std::mt19937_64 rng(12345);
     std::vector<uint32_t> oldh(n), nexth(n), idx(n);
     for (uint32_t i = 0; i < n; ++i) oldh[i] = (uint32_t)(rng() % (1u << bits)) & ~0x3u; // ~2.4 per used cell
