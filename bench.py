@@ -187,6 +187,7 @@ def developed_record(s, capi, n, skip, steps, steps_before, bpp, real_bytes, tor
         rec["hit_list_overflow_fraction"] = s.get_stat(capi.STAT_HIT_OVERFLOW) / n
         rec["neighbours_mean"] = s.get_stat(capi.STAT_HIT_MEAN)
         rec["neighbours_max"] = s.get_stat(capi.STAT_HIT_MAX)
+        rec["unstaged_fraction"] = s.get_stat(capi.STAT_UNSTAGED) / n
     except capi.NereusError as e:  # (reference-order kernels keep no hit lists)
         rec["stats_unavailable"] = str(e)
     dom = max(stages, key=stages.get) if stages else None
@@ -212,6 +213,9 @@ def main():
                     help="SReal: 32 (default, the reference's shipped build) or 64 (DOUBLE_PRECISION=1, config 5)")
     ap.add_argument("--kernel-set", default="muller", choices=["muller", "monaghan"],
                     help="KERNEL_SET: muller (default) or monaghan (config 5)")
+    ap.add_argument("--arith", default="exact", choices=["exact", "fast"],
+                    help="exact = every float sum in the reference's order with IEEE arithmetic (bit-identical to the CPU oracle); "
+                         "fast = NRS_FLAG_FAST_ARITH (tolerance mode, fp32 Muller SESPH; indices stay bit-exact)")
     ap.add_argument("--developed", type=int, default=None, metavar="SKIP",
                     help="N=1 SESPH: after the timed region run SKIP more untimed steps (default 600; 0 = off) and time "
                          "--developed-steps more: the `developed` sub-record of the JSON line (the dam has broken by then)")
@@ -271,7 +275,8 @@ def main():
     n = len(sc["pos"])
     stream = torch.cuda.current_stream().cuda_stream
     s = capi.Solver(p, n, solver=capi.IISPH if iisph else capi.SESPH, double=double, kernel_set=kset, device=local_rank,
-                    stream=stream, reference_order=args.reference_order, flags=capi.FLAG_FULL_SORT if args.full_sort else 0)
+                    stream=stream, reference_order=args.reference_order,
+                    flags=(capi.FLAG_FULL_SORT if args.full_sort else 0) | (capi.FLAG_FAST_ARITH if args.arith == "fast" else 0))
     s.set_particles(sc["pos"], sc["vel"])
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     P = s.params
@@ -340,6 +345,7 @@ def main():
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
             "kernels": "reference-order" if args.reference_order else "tiled",
+            "arith": args.arith if (not double and kset == capi.MULLER and not iisph and not args.reference_order) else "exact",
             "sort": dict(zip(("coherent_resort_steps", "fell_back_to_full_sort"), s.resort_stats())),
             "parallelism": "1 GPU",
         },

@@ -74,6 +74,13 @@ enum {
     NRS_FLAG_FULL_SORT = 1u << 4,       /* sort all (hash, index) pairs from scratch every step, as the reference does
                                            (sph_cuda.cu:310-313); default: only the particles that changed cell are
                                            sorted and merged into the still-sorted rest (same result, element for element) */
+    NRS_FLAG_FAST_ARITH = 1u << 5,      /* tolerance mode (fp32, Muller kernels, SESPH): reciprocals instead of IEEE divisions,
+                                           v_rsq instead of correctly rounded square roots, float powers, fused multiply-adds,
+                                           density summed inside the neighbour scan.  Hash / index / cell tables are unaffected
+                                           (calcGridPos keeps its true division); densities, forces and the integrated state agree
+                                           with the default reference-order IEEE arithmetic to ~1e-6 relative per step.  The
+                                           reference itself is built with --use_fast_math (CMakeLists.txt:85).  Ignored (exact
+                                           arithmetic) for fp64, Monaghan kernels, IISPH and NRS_FLAG_REFERENCE_ORDER. */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };
@@ -262,9 +269,18 @@ int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks);
  *                           last step sorted from scratch without counting)
  *   NRS_STAT_HIT_OVERFLOW   particles whose neighbour hit list overflowed (they take the reference-order cell walk)
  *   NRS_STAT_HIT_MEAN/_MAX  neighbours (fluid + boundary hits) per particle kept in the hit lists
- * The HIT_* values need the shared hit lists of the production kernels (NRS_E_STATE otherwise). */
-enum { NRS_STAT_MOVERS = 0, NRS_STAT_HIT_OVERFLOW = 1, NRS_STAT_HIT_MEAN = 2, NRS_STAT_HIT_MAX = 3 };
+ *   NRS_STAT_UNSTAGED       particles whose wavefront could not stage its neighbour rows in LDS (grid-edge cells, or
+ *                           hulls longer than the pool) and scanned them from global memory instead
+ * The HIT_* / UNSTAGED values need the shared hit lists of the production kernels (NRS_E_STATE otherwise). */
+enum { NRS_STAT_MOVERS = 0, NRS_STAT_HIT_OVERFLOW = 1, NRS_STAT_HIT_MEAN = 2, NRS_STAT_HIT_MAX = 3, NRS_STAT_UNSTAGED = 4 };
 int nrs_get_stat(nrs_ctx *ctx, int which, double *out);
+
+/* Akinci boundary volumes on the device (no context needed): vbi[i] = 1 / sum_k W_poly6(|x_i - x_k|, h) over the boundary
+ * particles k within h of i, i included — what the reference takes from its un-vendored submodule
+ * (sample_spheres::boundary_forces::getVbi, main.cpp:546; own implementation, parity unpinned).  bi4: nb xyzw particles of
+ * SReal (precision 32/64), vbi: nb SReal, both HOST buffers; device < 0 = current device.  Uses the same hash / radix sort /
+ * cell-range / 27-cell gather as the solver, on a private grid. */
+int nrs_boundary_volumes(int device, int precision, const void *bi4, uint64_t nb, double h, void *vbi);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);

@@ -12,7 +12,7 @@ import numpy as np
 from .params import params_dtype
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnereus_hip.so")
+LIB_PATH = os.environ.get("NEREUS_HIP_LIB") or os.path.join(_HERE, "libnereus_hip.so")  # (override: kernel A/B builds in tools/)
 
 SESPH, IISPH = 0, 1
 MONAGHAN, MULLER = 0, 1
@@ -20,8 +20,9 @@ FLAG_REFERENCE_ORDER = 1
 FLAG_NO_FUSION = 4
 FLAG_NO_SHARED_LISTS = 8
 FLAG_FULL_SORT = 16
+FLAG_FAST_ARITH = 32
 E_NOTREADY = -6
-STAT_MOVERS, STAT_HIT_OVERFLOW, STAT_HIT_MEAN, STAT_HIT_MAX = 0, 1, 2, 3
+STAT_MOVERS, STAT_HIT_OVERFLOW, STAT_HIT_MEAN, STAT_HIT_MAX, STAT_UNSTAGED = 0, 1, 2, 3, 4
 
 # NRS_STAGE_*
 STAGE_HASH, STAGE_SORT, STAGE_REORDER, STAGE_DENSITY, STAGE_FORCES, STAGE_INTEGRATE = 1, 2, 3, 4, 5, 6
@@ -49,7 +50,7 @@ EXPORTS = [
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
     "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats", "nrs_snapshot_begin", "nrs_snapshot_wait",
-    "nrs_get_stat",
+    "nrs_get_stat", "nrs_boundary_volumes",
 ]
 
 
@@ -114,6 +115,7 @@ def load_library(path=None):
     lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.nrs_resort_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.nrs_get_stat.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    lib.nrs_boundary_volumes.argtypes = [i32, i32, vp, u64, C.c_double, vp]
     lib.nrs_snapshot_begin.argtypes = [vp, i32]
     lib.nrs_snapshot_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     _lib = lib
@@ -122,6 +124,18 @@ def load_library(path=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def boundary_volumes(bi4, h, double=False, device=-1):
+    """Akinci volumes of the boundary particles bi4 (n,4) on the device (nrs_boundary_volumes); returns (n,) SReal."""
+    lib = load_library()
+    real = np.float64 if double else np.float32
+    bi4 = np.ascontiguousarray(bi4, dtype=real).reshape(-1, 4)
+    out = np.empty(bi4.shape[0], dtype=real)
+    rc = lib.nrs_boundary_volumes(int(device), 64 if double else 32, _ptr(bi4), bi4.shape[0], float(h), _ptr(out))
+    if rc != 0:
+        raise NereusError("libnereus_hip error %d: %s" % (rc, lib.nrs_last_error().decode()))
+    return out
 
 
 class Solver:

@@ -11,6 +11,8 @@
 
 #include "nrs_kernels_ref.h"
 #include "nrs_kernels_tiled.h"
+#include "nrs_kernels_staged.h"
+#include <type_traits>
 #include "nrs_kernels_iisph.h"
 #include "nrs_kernels_slab.h"
 #include "nrs_kernels_resort.h"
@@ -81,6 +83,20 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij, diiSum;
     DevBuf redPartial, redOut;
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
+    DevBuf fastQ;             // NRS_FLAG_FAST_ARITH: (p/rho^2, 1/rho) per sorted slot, density kernel -> force kernel
+    // LDS-staged density scan (nrs_kernels_staged.h): fp32 SESPH on power-of-two grids; NEREUS_STAGED=0 keeps the
+    // global-memory scan of nrs_kernels_tiled.h (A/B runs)
+    bool stagedScan() const
+    {
+        static const bool allow = !(getenv("NEREUS_STAGED") && atoi(getenv("NEREUS_STAGED")) == 0);
+        return allow && std::is_same<R, float>::value && !iisph() && !refOrder();
+    }
+    // fast arithmetic (reciprocals, rsq, fused multiply-adds, density summed in the scan): fp32 Muller SESPH on the
+    // production kernels with shared lists; everything else keeps the reference-order IEEE arithmetic
+    bool fastArith() const
+    {
+        return (cfg.flags & NRS_FLAG_FAST_ARITH) && std::is_same<R, float>::value && KSET == KS_MULLER && stagedScan() && hitBuf.p != nullptr;
+    }
     // coherent re-sort (nrs_kernels_resort.h)
     DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars, rsPrevPacked;
     bool slotOrderValid = false; // posA/velA are in the slot order of hashCur (a full fused step was the last thing that happened)
@@ -137,6 +153,49 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     uint32_t stageLaunches[NRS_STAGE_COUNT] = {0};
     bool evOpen = false;
 
+    // ---- the state of the particle arrays and of the keys prepared for the next step --------------------------------
+    // The fields above are not independent: they encode ONE of the states below (DESIGN.md §5 has the transition table).
+    // Every public entry point calls validate() first, so a sequence of calls that would leave them inconsistent returns
+    // NRS_E_STATE instead of handing a wrong count or a stale table to a kernel (the GPU memory fault of round 1 was exactly
+    // that: a merge sized with a mover count that had been reset before it was read).
+    enum ArrayState {
+        AS_FRESH,        // arrays compact, any order; the next step hashes and sorts from scratch
+        AS_KEYS_READY,   // + hashNext/indexNext hold the next step's keys/values (fused kernel, or slab pack/unpack)
+        AS_SPLIT_QUEUED, // + their movers/stayers split is queued (coherent re-sort); the count is pending or known
+        AS_SLOT_ORDER,   // slab run after a fused step: arrays in the slot order of hashCur, keys per slot, to be re-partitioned
+        AS_HOLES,        // slab in-place partition: arrays [0, physN) with dead slots, split queued, count known
+        AS_INVALID
+    };
+    ArrayState array_state() const
+    {
+        if (n > cap || (slabOn && nOwned > n)) return AS_INVALID;
+        if (!slabOn && (holesPending || classifiedValid)) return AS_INVALID;
+        if (hashReady && (!hashNext || !indexNext)) return AS_INVALID;
+        if (rsPending && (!hashReady || !rsMovers.p)) return AS_INVALID;
+        if (rsCountKnown && !rsPending) return AS_INVALID;
+        if (classifiedValid && (!slotOrderValid || !hashCur || !hashNext)) return AS_INVALID;
+        if (slotOrderValid && (!hashCur || !hashNext)) return AS_INVALID;
+        if (holesPending) {
+            if (!(packInplace && hashReady && rsPending && rsCountKnown) || physN < n || physN > cap || rsKnownCount > physN) return AS_INVALID;
+            return AS_HOLES;
+        }
+        if (rsCountKnown && rsKnownCount > n) return AS_INVALID;
+        if (rsPending) return AS_SPLIT_QUEUED;
+        if (hashReady) return AS_KEYS_READY;
+        if (slotOrderValid) return AS_SLOT_ORDER;
+        return AS_FRESH;
+    }
+    int validate(const char *where) const
+    {
+        if (array_state() != AS_INVALID) return NRS_OK;
+        char buf[320];
+        snprintf(buf, sizeof(buf), "internal state inconsistent at %s (n %llu cap %llu physN %u owned %llu | hashReady %d rsPending %d countKnown %d "
+                 "known %u holes %d inplace %d classified %d slotOrder %d slab %d)", where, (unsigned long long)n, (unsigned long long)cap, physN,
+                 (unsigned long long)nOwned, hashReady, rsPending, rsCountKnown, rsKnownCount, holesPending, packInplace, classifiedValid,
+                 slotOrderValid, slabOn);
+        return fail(NRS_E_STATE, buf);
+    }
+
     // the tiled kernels assume the power-of-two grids the reference's hash assumes (sph_kernel_impl.cuh:120)
     bool refOrder() const
     {
@@ -153,7 +212,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &hitBuf, &hitCounts, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &hitBuf, &hitCounts, &fastQ, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -211,6 +270,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if ((!iisph() || KSET == KS_MULLER) && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_SHARED_LISTS))) {
             NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
             NRSCHK(hitCounts.alloc((size_t)cap * 4));
+            if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
+                NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
         NRSCHK(redPartial.alloc(sizeof(double) * 1024));
         NRSCHK(redOut.alloc(sizeof(double)));
@@ -292,6 +353,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int upload(const void *pos4, const void *vel4, const void *pres, uint64_t first, uint64_t count) override
     {
+        NRSCHK(validate("nrs_upload_particles"));
         if (first + count > cap) return fail(NRS_E_CAPACITY, "upload exceeds capacity");
         NRSCHK(compact_holes());
         if (count) {
@@ -304,17 +366,20 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             HIPCHK(hipStreamSynchronize(stream)); // the caller may reuse its host buffers on return
         }
         if (first + count > n) n = first + count;
+        if (slabOn) nOwned = n; // (until the next partition says otherwise)
         midStep = false;
-        hashReady = false;
-        slotOrderValid = false;
+        hashReady = false; rsPending = false; rsCountKnown = false;
+        slotOrderValid = false; classifiedValid = false;
         return NRS_OK;
     }
     int set_n(uint64_t nn) override
     {
+        NRSCHK(validate("nrs_set_num_particles"));
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
         NRSCHK(compact_holes());
-        if (nn != n) { hashReady = false; slotOrderValid = false; }
+        if (nn != n) { hashReady = false; rsPending = false; rsCountKnown = false; slotOrderValid = false; classifiedValid = false; }
         n = nn;
+        if (slabOn) nOwned = n;
         return NRS_OK;
     }
     uint64_t get_n() override { return n; }
@@ -512,6 +577,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             if (!countKnown) NRSCHK(wait_mover_count(&M));
             ++rsSteps;
             lastMovers = (double)M;
+            if (M > N) return fail(NRS_E_STATE, "coherent re-sort: mover count exceeds the particle count (stale count)");
             if (few_movers(M, N)) {
                 if (M == 0) {
                     merged = rsStayers.as<uint64_t>();
@@ -628,7 +694,17 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         const bool share = !refOrder() && hitBuf.p && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
-        if (refOrder())
+        const bool fast = fastArith() && share && fastQ.p;
+        bool didStaged = false;
+        if constexpr (std::is_same<R, float>::value) {
+            if (stagedScan()) {
+                launch_density_staged<KSET, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, fast, posB.as<T4>(), dens.as<R>(),
+                                                   presB.as<R>(), fast ? fastQ.as<FastPair>() : (FastPair *)nullptr, N);
+                didStaged = true;
+            }
+        }
+        if (didStaged) {
+        } else if (refOrder())
             hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         else
             launch_density_tiled<R, KSET, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(), dens.as<R>(),
@@ -672,8 +748,17 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 classifiedN = N;
                 rsTilesDirty = true; // until a pack's scan consumes the tile counts
             }
-            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
-                                                      velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
+            bool didFast = false;
+            if constexpr (std::is_same<R, float>::value && KSET == KS_MULLER) {
+                if (fast) {
+                    launch_forces_fast<SURF, HAS_B>(stream, P, G, hb, posB.as<T4>(), velB.as<T4>(), dens.as<R>(), presB.as<R>(),
+                                                    fastQ.as<FastPair>(), (T4 *)nullptr, &fo, N);
+                    didFast = true;
+                }
+            }
+            if (!didFast)
+                launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
+                                                          velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
             hashNext = fo.hash; indexNext = fo.index;
             hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
             fusedThisStep = true;
@@ -682,9 +767,18 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 NRSCHK(queue_resort_split(N));
             }
         } else {
-            launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
-                                                      velB.as<T4>(), dens.as<R>(), presB.as<R>(), forces.as<T4>(),
-                                                      (const FusedOut<R> *)nullptr, N);
+            bool didFast = false;
+            if constexpr (std::is_same<R, float>::value && KSET == KS_MULLER) {
+                if (fast) {
+                    launch_forces_fast<SURF, HAS_B>(stream, P, G, hb, posB.as<T4>(), velB.as<T4>(), dens.as<R>(), presB.as<R>(),
+                                                    fastQ.as<FastPair>(), forces.as<T4>(), (const FusedOut<float> *)nullptr, N);
+                    didFast = true;
+                }
+            }
+            if (!didFast)
+                launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
+                                                          velB.as<T4>(), dens.as<R>(), presB.as<R>(), forces.as<T4>(),
+                                                          (const FusedOut<R> *)nullptr, N);
         }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_FORCES || fuse) return NRS_OK;
@@ -850,6 +944,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int slab_pack(void *sendL, void *sendR, uint64_t mcap, uint32_t *counts) override
     {
+        NRSCHK(validate("nrs_slab_pack"));
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
         if (mcap == 0 || mcap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
@@ -1001,6 +1096,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int slab_unpack(const void *recvL, const void *recvR, uint64_t mcap) override
     {
+        NRSCHK(validate("nrs_slab_unpack"));
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
         uint32_t hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
         if (recvL) HIPCHK(hipMemcpyAsync(hL, recvL, 16, hipMemcpyDeviceToHost, stream));
@@ -1085,20 +1181,22 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int get_stat(int which, double *out) override
     {
         if (which == NRS_STAT_MOVERS) { *out = lastMovers; return NRS_OK; }
-        if (which != NRS_STAT_HIT_OVERFLOW && which != NRS_STAT_HIT_MEAN && which != NRS_STAT_HIT_MAX) return fail(NRS_E_INVALID, "unknown statistic");
+        if (which != NRS_STAT_HIT_OVERFLOW && which != NRS_STAT_HIT_MEAN && which != NRS_STAT_HIT_MAX && which != NRS_STAT_UNSTAGED)
+            return fail(NRS_E_INVALID, "unknown statistic");
         if (!hitCounts.p || !n || midStep) return fail(NRS_E_STATE, "no shared hit lists (reference-order kernels, or no step yet)");
         const uint32_t N = (uint32_t)n;
-        HIPCHK(hipMemsetAsync(redPartial.p, 0, 3 * sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(redPartial.p, 0, 4 * sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(k_hit_stats, dim3(std::min<uint32_t>(1024u, nblocks(N))), dim3(BLOCK), 0, stream, hitCounts.as<uint32_t>(),
                            (unsigned long long *)redPartial.p, N);
-        unsigned long long h[3] = {0, 0, 0};
+        unsigned long long h[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(h, redPartial.p, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        *out = which == NRS_STAT_HIT_OVERFLOW ? (double)h[0] : (which == NRS_STAT_HIT_MEAN ? (double)h[1] / (double)N : (double)h[2]);
+        *out = which == NRS_STAT_HIT_OVERFLOW ? (double)h[0] : (which == NRS_STAT_HIT_MEAN ? (double)h[1] / (double)N : (which == NRS_STAT_HIT_MAX ? (double)h[2] : (double)h[3]));
         return NRS_OK;
     }
     int step(int nsteps, int stop) override
     {
+        NRSCHK(validate("nrs_step"));
         if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
         if (n == 0) return NRS_OK;
         for (int s = 0; s < nsteps; ++s) {
@@ -1162,6 +1260,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     }
     int snapshot_begin(int withVel) override
     {
+        NRSCHK(validate("nrs_snapshot_begin"));
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
         NRSCHK(compact_holes());
         if (!copyStream) HIPCHK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
@@ -1220,6 +1319,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int download(void *pos4, void *vel4, void *pres) override
     {
+        NRSCHK(validate("nrs_download"));
         NRSCHK(compact_holes());
         if (pos4) HIPCHK(hipMemcpyAsync(pos4, posA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
         if (vel4) HIPCHK(hipMemcpyAsync(vel4, velA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));

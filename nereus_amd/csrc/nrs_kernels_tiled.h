@@ -51,6 +51,20 @@ struct CutThresholds { float lenLtIr, r2LeH2; };
 #ifndef FORCES_LISTS_MIN_WAVES
 #define FORCES_LISTS_MIN_WAVES 7
 #endif
+#ifndef FORCES_COOP_LANES
+#define FORCES_COOP_LANES 4 // up to this many lanes of a wave with boundary hits: their pair terms are evaluated by the whole wave
+#endif
+#ifndef SCAN_COOP_LANES
+#define SCAN_COOP_LANES 4 // up to this many lanes of a wave with boundary cells: the wave sweeps them cooperatively
+#endif
+// value of `v` in lane `srcLane` (wave-uniform lane number), for every lane
+NRS_DEV float bcast_lane(float v, int srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane)); }
+NRS_DEV double bcast_lane(double v, int srcLane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srcLane), hi = __builtin_amdgcn_readlane((int)(b >> 32), srcLane);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
 constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (6: 79 VGPRs = 6 waves, 0.81 vs 0.71 ms; 8: slower still)
 
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
@@ -157,7 +171,53 @@ template <typename R> struct Sweep {
             }
             if (HAS_B) {
                 anyB = anyB || bmask != 0u;
-                // boundary cells of this plane, visited in ascending cell number by the lanes that have any
+                // Boundary cells of this plane, in ascending cell number.  A wall usually touches a wave with one or two lanes
+                // (the first particles of an x-row), each with ~20-30 boundary candidates per plane: swept lane by lane that is
+                // 6-8 rounds of global loads per plane at 2/64 lane utilisation (measured: 37 % of the density kernel's time on
+                // the dam-break).  When few lanes have boundary cells, the whole wave sweeps them for one such lane at a time —
+                // 64 candidates per round, coalesced — ranks the hits with a ballot and stores them into that lane's list:
+                // the same entries in the same order.
+                const unsigned long long wall = __ballot(bmask != 0u);
+                if (wall != 0ull && __popcll(wall) <= SCAN_COOP_LANES) {
+                    const uint32_t lane = tid & 63u, tid0 = tid & ~63u;
+                    unsigned long long todo = wall;
+                    while (todo) {
+                        const int Ln = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        V3<R> q;
+                        q.x = bcast_lane(p.x, Ln); q.y = bcast_lane(p.y, Ln); q.z = bcast_lane(p.z, Ln);
+                        uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)bmask, Ln);
+                        const uint32_t x0L = (uint32_t)__builtin_amdgcn_readlane((int)x0, Ln), cxL = (uint32_t)__builtin_amdgcn_readlane((int)cx, Ln),
+                                       x2L = (uint32_t)__builtin_amdgcn_readlane((int)x2, Ln);
+                        const int gyL = __builtin_amdgcn_readlane(gp.y, Ln);
+                        const uint32_t planeL = (uint32_t)__builtin_amdgcn_readlane((int)plane, Ln);
+                        const int room = HIT_CAP - __builtin_amdgcn_readlane(nf, Ln); // list slots the fluid hits left
+                        int nbL = __builtin_amdgcn_readlane(nb, Ln);
+                        while (bm) {
+                            const int bit = __builtin_ctz(bm);
+                            bm &= bm - 1u;
+                            const int y = bit / 3, c = bit - y * 3;
+                            const uint32_t cyL = (uint32_t)(gyL + y - 1) & my;
+                            const uint32_t hc2 = planeL + umul24(cyL, P.gridSize[0]) + (c == 0 ? x0L : (c == 1 ? cxL : x2L));
+                            const uint32_t a = G.bCellStart[hc2], nT = G.bCellEnd[hc2] - a;
+                            const uint32_t tag = (uint32_t)((z + 1) * 9 + bit);
+                            for (uint32_t base = 0; base < nT; base += 64u) {
+                                const uint32_t qi = base + lane;
+                                const bool valid = qi < nT;
+                                const T4 cb = G.sB[a + (valid ? qi : 0u)];
+                                const V3<R> d = q - xyz<R>(cb);
+                                const bool hit = valid & (dot(d, d) < tB);
+                                const unsigned long long hm = __ballot(hit);
+                                if (hit) {
+                                    const int k = nbL + (int)__popcll(hm & ((1ull << lane) - 1ull));
+                                    if (k < room) lst[HIT_CAP - 1 - k][tid0 + (uint32_t)Ln] = (a + qi) | (tag << HIT_TAG_SHIFT);
+                                }
+                                nbL += (int)__popcll(hm);
+                            }
+                        }
+                        if (lane == (uint32_t)Ln) { nb = nbL; over = over || (nbL > room); }
+                    }
+                } else
                 while (bmask) {
                     const int bit = __builtin_ctz(bmask);
                     bmask &= bmask - 1u;
@@ -207,6 +267,7 @@ struct HitMerge {
         headF = nf > 0 ? base[0] : 0xffffffffu;
         headB = nb > 0 ? base[(uint32_t)(HIT_CAP - 1) * stride] : 0xffffffffu;
     }
+    NRS_DEV int last_boundary() const { return kb - 1; } // visiting number of the boundary hit next() just handed out
     NRS_DEV bool next(uint32_t &index, bool &boundary, uint32_t &key)
     {
         if (kf >= nf && kb >= nb) return false;
@@ -261,13 +322,48 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
     return d;
 }
 
+// The three boundary terms of one (fluid particle, boundary particle) pair, computeCellForces sph_kernel_impl.cuh:566-602:
+// adhesion, pressure mirror, friction — evaluated here ONCE, by whichever lane does it (the owner, or a helper lane of the
+// cooperative pre-pass of k_forces_lists), with the same operations in the same order; the owner adds them to its running
+// sums in the reference's order.
+template <typename R, int KSET> struct BoundaryTerms { V3<R> bound, pres, visc; };
+template <typename R, int KSET>
+NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3<R> vel1, R dens, R pres, typename Vec4T<R>::type bq)
+{
+    const R pm = P.particleMass, ir = P.interactionRadius;
+    const R epsilon = (R)0.01;
+    const R beta = P.beta, rd = P.restDensity;
+    const R psi = (rd * bq.w);
+    const V3<R> p1p2 = pos1 - xyz<R>(bq);
+    const V3<R> v1v2 = vel1;
+    R kernel;
+    V3<R> grad;
+    if (KSET == KS_MONAGHAN) {
+        kernel = Wmonaghan<R>(p1p2, ir);
+        grad = Wmonaghan_grad<R>(p1p2, ir);
+    } else {
+        kernel = Wdefault<R>(p1p2, ir, P.kpoly);
+        grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+    }
+    BoundaryTerms<R, KSET> T;
+    T.bound = (beta * psi * p1p2 * kernel);
+    T.pres = (-pm * psi * (pres / (dens * dens)) * grad);
+    const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
+    const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
+    const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
+    const R Pij = -nu * (nom / denom);
+    T.visc = (pm * psi * Pij * grad);
+    return T;
+}
+
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
 template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sPos,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
-                                     const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu)
+                                     const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu,
+                                     const R *pre = nullptr)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -287,26 +383,16 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
     bool isB;
     while (it.next(j, isB, key)) {
         if (HAS_B && isB) {
-            const typename Vec4T<R>::type bq = G.sB[j];
-            const R psi = (rd * bq.w);
-            const V3<R> p1p2 = pos1 - xyz<R>(bq);
-            const V3<R> v1v2 = vel1;
-            R kernel;
-            V3<R> grad;
-            if (KSET == KS_MONAGHAN) {
-                kernel = Wmonaghan<R>(p1p2, ir);
-                grad = Wmonaghan_grad<R>(p1p2, ir);
+            BoundaryTerms<R, KSET> T;
+            if (pre) { // evaluated by the cooperative pre-pass (same operations): pre[k][0..8]
+                const R *t = pre + (size_t)it.last_boundary() * 9;
+                T.bound = mk3<R>(t[0], t[1], t[2]); T.pres = mk3<R>(t[3], t[4], t[5]); T.visc = mk3<R>(t[6], t[7], t[8]);
             } else {
-                kernel = Wdefault<R>(p1p2, ir, P.kpoly);
-                grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+                T = boundary_terms<R, KSET>(P, pos1, vel1, dens, pres, G.sB[j]);
             }
-            A.fbound = A.fbound + (beta * psi * p1p2 * kernel);
-            A.fpres = A.fpres + (-pm * psi * (pres / (dens * dens)) * grad);
-            const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
-            const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
-            const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
-            const R Pij = -nu * (nom / denom);
-            A.fvisc = A.fvisc - (pm * psi * Pij * grad);
+            A.fbound = A.fbound + T.bound;
+            A.fpres = A.fpres + T.pres;
+            A.fvisc = A.fvisc - T.visc;
         } else {
             const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
             if (STRICT && ((j == self) || !(length(p1p2) < ir))) continue; // the loop's own tests (:494,:505)
@@ -359,6 +445,7 @@ NRS_DEV uint32_t pack_counts(HitCounts hc)
 {
     return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u) | (hc.anyB ? 1u << 17 : 0u);
 }
+constexpr uint32_t COUNTS_UNSTAGED = 1u << 18; // diagnostics: the particle's wave took the global-memory scan (nrs_kernels_staged.h)
 NRS_DEV HitCounts unpack_counts(uint32_t c)
 {
     HitCounts hc;
@@ -368,12 +455,14 @@ NRS_DEV HitCounts unpack_counts(uint32_t c)
 }
 
 // diagnostics over the published hit counts: out[0] = particles whose list overflowed, out[1] = sum of hits (lists that
-// did not overflow), out[2] = longest list
+// did not overflow), out[2] = longest list, out[3] = particles whose wave could not stage its neighbour rows in LDS
 static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__restrict__ counts, unsigned long long *__restrict__ out, uint32_t n)
 {
-    unsigned long long over = 0, sum = 0, mx = 0;
+    unsigned long long over = 0, sum = 0, mx = 0, unst = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const HitCounts hc = unpack_counts(counts[i]);
+        const uint32_t c = counts[i];
+        const HitCounts hc = unpack_counts(c);
+        unst += (c & COUNTS_UNSTAGED) ? 1ull : 0ull;
         if (hc.over) { ++over; continue; }
         const unsigned long long k = (unsigned long long)(hc.nf + hc.nb);
         sum += k;
@@ -382,6 +471,7 @@ static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__re
     for (int d = 32; d >= 1; d >>= 1) {
         over += __shfl_down(over, d);
         sum += __shfl_down(sum, d);
+        unst += __shfl_down(unst, d);
         const unsigned long long o = __shfl_down(mx, d);
         mx = o > mx ? o : mx;
     }
@@ -389,6 +479,7 @@ static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__re
         atomicAdd(&out[0], over);
         atomicAdd(&out[1], sum);
         atomicMax(&out[2], mx);
+        atomicAdd(&out[3], unst);
     }
 }
 
@@ -527,18 +618,56 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? FORCES_LISTS_MIN_WAVES : 1
                                                         uint32_t n)
 {
     typedef typename Vec4T<R>::type T4;
+    // Boundary hits belong to the one or two lanes of a wave that sit at a wall (up to HIT_CAP each, ~250 instructions per hit
+    // with the reference's divisions): when few lanes have any, their pair terms are evaluated by the whole wave first — lane t
+    // takes hit t — and parked in LDS; the owner then adds them in the reference's order while it walks its lists.
+    __shared__ R bterm[HAS_B ? BLOCK / 64 : 1][HAS_B ? FORCES_COOP_LANES : 1][HAS_B ? HIT_CAP : 1][9];
     const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
     if (i >= n) return;
     const T4 p4 = sPos[i];
     const T4 v4 = sVel[i];
     const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
     V3<R> f = mk3<R>(0, 0, 0);
-    if (slab_active<R>(P, G, pos1.x)) {
-        const R dens = sDens[i], pres = sPres[i];
-        const HitCounts hc = unpack_counts(hb.counts[i]);
+    const bool active = slab_active<R>(P, G, pos1.x);
+    R dens = (R)0, pres = (R)0;
+    HitCounts hc;
+    hc.nf = 0; hc.nb = 0; hc.over = false; hc.anyB = false;
+    if (active) { dens = sDens[i]; pres = sPres[i]; hc = unpack_counts(hb.counts[i]); }
+    const R *pre = nullptr;
+    if (HAS_B) {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const int nbMine = (active && !hc.over) ? hc.nb : 0;
+        const unsigned long long wall = __ballot(nbMine > 0);
+        if (wall != 0ull && __popcll(wall) <= FORCES_COOP_LANES) {
+            unsigned long long todo = wall;
+            int s = 0;
+            while (todo) {
+                const int Ln = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int nbL = __builtin_amdgcn_readlane(nbMine, Ln);
+                const uint32_t iL = (uint32_t)__builtin_amdgcn_readlane((int)i, Ln);
+                V3<R> pl, vl;
+                pl.x = bcast_lane(pos1.x, Ln); pl.y = bcast_lane(pos1.y, Ln); pl.z = bcast_lane(pos1.z, Ln);
+                vl.x = bcast_lane(vel1.x, Ln); vl.y = bcast_lane(vel1.y, Ln); vl.z = bcast_lane(vel1.z, Ln);
+                const R dl = bcast_lane(dens, Ln), prl = bcast_lane(pres, Ln);
+                if ((int)lane < nbL) { // nbL <= HIT_CAP < 64: one round; hit t of the owner = list slot HIT_CAP-1-t
+                    const uint32_t j = hb.hits[(size_t)(HIT_CAP - 1 - (int)lane) * hb.stride + iL] & HIT_INDEX;
+                    const BoundaryTerms<R, KSET> T = boundary_terms<R, KSET>(P, pl, vl, dl, prl, G.sB[j]);
+                    R *t = &bterm[wave][s][lane][0];
+                    t[0] = T.bound.x; t[1] = T.bound.y; t[2] = T.bound.z;
+                    t[3] = T.pres.x; t[4] = T.pres.y; t[5] = T.pres.z;
+                    t[6] = T.visc.x; t[7] = T.visc.y; t[8] = T.visc.z;
+                }
+                if (lane == (uint32_t)Ln) pre = &bterm[wave][s][0][0];
+                ++s;
+            }
+        }
+    }
+    if (active) {
         ForceAcc<R> A;
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc,
+                                                        0xffffffffu, pre);
         f = sesph_total_force<R>(P, A, dens);
     }
     forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);

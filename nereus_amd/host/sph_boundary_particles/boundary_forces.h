@@ -6,14 +6,19 @@
 #include <cstdint>
 #include <vector>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
+#include "nereus_hip.h"
 
 namespace sample_spheres {
 namespace boundary_forces {
 
 // vbi[b] = 1 / sum_k W_poly6(|x_b - x_k|, h) over all boundary particles k within h of b (b itself included)
-// (Akinci et al. 2012, eq. 4).  Uniform-grid search on the host, O(n * neighbours).
-inline void getVbi(std::vector<SReal> &vbi, std::vector<SVec4> &bi, SReal h)
+// (Akinci et al. 2012, eq. 4).  Uniform-grid search on the HOST, O(n * neighbours): kept as the cross-check of the device
+// version below (tests/test_host_class.py), not called by the product path.
+inline void getVbiHost(std::vector<SReal> &vbi, std::vector<SVec4> &bi, SReal h)
 {
     const size_t n = bi.size();
     vbi.assign(n, (SReal)0);
@@ -42,6 +47,19 @@ inline void getVbi(std::vector<SReal> &vbi, std::vector<SVec4> &bi, SReal h)
             }
         }
         vbi[i] = (SReal)(1.0 / acc);
+    }
+}
+
+// The signature main.cpp:546 calls.  Runs on the device (nrs_boundary_volumes: the solver's own hash / sort / cell-range /
+// 27-cell gather machinery); like every call of the reference's launcher layer it is fatal on error.
+inline void getVbi(std::vector<SReal> &vbi, std::vector<SVec4> &bi, SReal h)
+{
+    vbi.assign(bi.size(), (SReal)0);
+    if (bi.empty()) return;
+    const int rc = nrs_boundary_volumes(-1, (int)(8 * sizeof(SReal)), bi.data(), (uint64_t)bi.size(), (double)h, vbi.data());
+    if (rc != 0) {
+        std::fprintf(stderr, "getVbi: nrs_boundary_volumes failed (%d): %s\n", rc, nrs_last_error());
+        std::exit(EXIT_FAILURE);
     }
 }
 

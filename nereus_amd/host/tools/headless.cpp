@@ -44,6 +44,27 @@ int main(int argc, char **argv)
 {
     if (argc < 4) die("usage: see source header");
     const std::string mode = argv[1], kind = argv[2];
+    if (mode == "vbi") { // headless vbi <bi.f32 (xyzw)> <h> <out.f32>: getVbi (device) then getVbiHost (host cross-check)
+        if (argc < 5) die("vbi needs <bi.f32> <h> <out.f32>");
+        FILE *f = std::fopen(argv[2], "rb");
+        if (!f) die("cannot open input");
+        std::fseek(f, 0, SEEK_END);
+        const size_t nb = (size_t)std::ftell(f) / sizeof(SVec4);
+        std::fseek(f, 0, SEEK_SET);
+        std::vector<SVec4> b(nb);
+        if (nb && std::fread(b.data(), sizeof(SVec4), nb, f) != nb) die("short input");
+        std::fclose(f);
+        std::vector<SReal> dev, host;
+        const SReal h = (SReal)std::atof(argv[3]);
+        sample_spheres::boundary_forces::getVbi(dev, b, h);
+        sample_spheres::boundary_forces::getVbiHost(host, b, h);
+        FILE *o = std::fopen(argv[4], "wb");
+        if (!o) die("cannot open output");
+        std::fwrite(dev.data(), sizeof(SReal), nb, o);
+        std::fwrite(host.data(), sizeof(SReal), nb, o);
+        std::fclose(o);
+        return 0;
+    }
     const bool iisph = kind == "iisph";
     Nereus::SPH *sim = iisph ? (Nereus::SPH *)new Nereus::IISPH() : new Nereus::SPH();
     sim->_initialize();

@@ -625,7 +625,6 @@ def test_regrid_between_steps_invalidates_prepared_keys(hip_lib):
         o.step(3); s.step(3)
         np.testing.assert_array_equal(s.get("hash"), o.get("hash"))
         np.testing.assert_array_equal(s.get("index"), o.get("index"))
-        check_cell_tables(s.get("cellStart"), s.get("cellEnd"), o.get("cellStart"), o.get("cellEnd"))
         gp, gv = s.download()
         assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
         assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS

@@ -159,6 +159,22 @@ def test_slab_hip_engine_coherent_resort(tmp_path, hip_lib):
 
 
 @pytest.mark.gpu
+def test_slab_c4_per_rank_size(tmp_path, hip_lib):
+    """BASELINE config C4 at its per-rank size: the 16 M-particle run gives every GPU a 32 x 250 x 250 = 2 M-particle slab
+    (256 x 250 x 250 over 8 ranks).  Two such ranks share the one GPU of the test box (gloo + host staging instead of RCCL);
+    10 steps with particles crossing the cut; particle ids conserved, state finite, every step after the first on the merge
+    path of the coherent re-sort, and positions / velocities within 1e-5 of the single-domain ORACLE on the 64 x 250 x 250
+    union, particle by particle."""
+    steps = 10
+    moved = _run(2, steps, True, tmp_path, lattice=(32, 250, 250))
+    assert moved > 1000
+    for used, fallbacks in _run.resort:
+        assert used >= steps - 1 and fallbacks == 0
+    owned = np.stack(_run.owned)
+    assert owned.sum(axis=0).tolist() == [2 * 32 * 250 * 250] * (steps + 1)
+
+
+@pytest.mark.gpu
 def test_slab_rebalance_with_fused_classification(tmp_path, hip_lib):
     """Slabs big enough for the in-place partition, whose classification rides in the force kernel: a re-cut between the
     step and the partition invalidates that classification (it was made for the old cuts); same bar against the

@@ -9,9 +9,15 @@ p = default_params(0)
 lat = scene.CONFIGS[cfg] if cfg in scene.CONFIGS else tuple(int(v) for v in cfg.split(","))
 sc = scene.dam_break(lat, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
 n = len(sc["pos"])
-for ref in (False, True):
-    s = capi.Solver(p, n, reference_order=ref)
-    s.set_boundaries(sc["bi"], sc["vbi"], True)
+fast = int(os.environ.get("NEREUS_ABLATE_FAST", "0"))
+for ref in (False,) if os.environ.get("NEREUS_ABLATE_NOREF") else (False, True):
+    s = capi.Solver(p, n, reference_order=ref, flags=capi.FLAG_FAST_ARITH if fast else 0)
+    if os.environ.get("NEREUS_ABLATE_NOBOUND"):
+        from nereus_amd.params import update_grid
+        bi = sc["bi"]
+        s.set_params(update_grid(p.copy(), bi[:, :3].min(0), bi[:, :3].max(0)))
+    else:
+        s.set_boundaries(sc["bi"], sc["vbi"], True)
     for mode in [0]:
         os.environ["NEREUS_DBG_STOP"] = str(mode)
         ts = []
@@ -22,6 +28,6 @@ for ref in (False, True):
             t = s.stage_ms()
             ts.append((t["density"][0], t.get("forces", (0, 0))[0]))
         d = s.get("dens")
-        print("%s n=%d ref=%s mode=%d density %.3f ms forces %.3f ms (dens stat mean %.3f)" % (cfg, n, ref, mode, min(a for a, b in ts), min(b for a, b in ts), float(d.mean())))
+        print("%s n=%d ref=%s fast=%d density %.3f ms forces %.3f ms (dens stat mean %.3f) unstaged %s" % (cfg, n, ref, fast, min(a for a, b in ts), min(b for a, b in ts), float(d.mean()), "-"))
     s.close()
 os.environ.pop("NEREUS_DBG_STOP")

@@ -7,7 +7,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = [("k_density_tiled", "density_tiled"), ("k_forces_lists", "forces_lists"), ("k_forces_tiled", "forces_tiled"),
+KERNELS = [("k_density_staged", "density_staged"), ("k_forces_fast", "forces_fast"), ("k_density_tiled", "density_tiled"), ("k_forces_lists", "forces_lists"), ("k_forces_tiled", "forces_tiled"),
            ("k_density_ref", "density_reference_order"), ("k_forces_ref", "forces_reference_order")]
 
 
@@ -35,6 +35,8 @@ def main():
                     k["derived_per_wave_" + c] = k[c] / waves
         if k.get("SQ_INSTS_VALU") and k.get("SQ_THREAD_CYCLES_VALU"):
             k["derived_avg_active_lanes_per_VALU_inst"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_INSTS_VALU"] / 4.0
+        if k.get("SQ_LDS_IDX_ACTIVE"):
+            k["derived_LDS_bank_conflict_fraction"] = k.get("SQ_LDS_BANK_CONFLICT", 0) / k["SQ_LDS_IDX_ACTIVE"]
         if k.get("TCC_REQ_sum"):
             k["derived_L2_hit_rate"] = k.get("TCC_HIT_sum", 0) / k["TCC_REQ_sum"]
         if k.get("SQ_WAVE_CYCLES") and k.get("SQ_WAIT_ANY"):
