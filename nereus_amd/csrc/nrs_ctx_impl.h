@@ -82,14 +82,43 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     // IISPH
     DevBuf densAdv, densCorr, P_l, P_l2, aii, velAdv, forcesAdv, forcesP, diiF, diiB, sumDij, diiSum;
     DevBuf redPartial, redOut;
+    DevBuf errWord; // set by the device-side consistency guard of the scans (GridView::err)
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
+    // wall-particle deferral (nrs_kernels_tiled.h): static near-boundary bit per cell, this step's wall list
+    DevBuf nearBits, wallList, wallTile, wallTileOffset, wallGroupTotal, wallGroupPrefix, wallScalars;
+    bool nearBitsValid = false;
+    bool wallListed = false; // this step's gathers run with wall workgroups
+    bool deferWalls() const
+    {
+        static const bool allow = !(getenv("NEREUS_WALL_PASS") && atoi(getenv("NEREUS_WALL_PASS")) == 0);
+        return allow && nearBitsValid && nb != 0 && !iisph() && !refOrder() && hitBuf.p != nullptr;
+    }
+    WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1}; }
+    // this step's wall list from the sorted keys: tile counts -> two-level scan (the re-sort's scan kernel) -> stable compaction
+    int build_wall_list(uint32_t N)
+    {
+        const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+        const WallList wl = wall_view();
+        hipLaunchKernelGGL(k_wall_count, dim3(nTiles), dim3(BLOCK), 0, stream, wl, wallTile.as<uint32_t>(), N);
+        uint32_t *sc = wallScalars.as<uint32_t>();
+        const ResortScan a = {wallTile.as<uint32_t>(), wallTileOffset.as<uint32_t>(), wallGroupTotal.as<uint32_t>(), wallGroupPrefix.as<uint32_t>(), sc + 1};
+        const ResortScan none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_resort_scan_tiles, dim3(nGroups), dim3(RESORT_GROUP), 0, stream, a, none, sc, (volatile uint64_t *)nullptr, 0u, nTiles);
+        hipLaunchKernelGGL(k_wall_compact, dim3(nTiles), dim3(BLOCK), 0, stream, wl, wallTileOffset.as<uint32_t>(), wallGroupPrefix.as<uint32_t>(),
+                           (uint32_t)RESORT_GROUP, wallList.as<uint32_t>(), N);
+        HIPCHK(hipGetLastError());
+        return NRS_OK;
+    }
     DevBuf fastQ;             // NRS_FLAG_FAST_ARITH: (p/rho^2, 1/rho) per sorted slot, density kernel -> force kernel
-    // LDS-staged density scan (nrs_kernels_staged.h): fp32 SESPH on power-of-two grids; NEREUS_STAGED=0 keeps the
-    // global-memory scan of nrs_kernels_tiled.h (A/B runs)
+    // LDS-staged density scan (nrs_kernels_staged.h): fp32 SESPH on power-of-two grids.  Measured at 10 M particles it is
+    // SLOWER than the global-memory scan in the exact arithmetic (0.84 vs 0.71 ms: the kernel is bound by vector-instruction
+    // issue, not by the latency the staging removes) and on par with it in the fast arithmetic, whose in-scan
+    // density sum it carries: it runs for NRS_FLAG_FAST_ARITH contexts only (NEREUS_STAGED=1 forces it, =0 forbids it).
     bool stagedScan() const
     {
-        static const bool allow = !(getenv("NEREUS_STAGED") && atoi(getenv("NEREUS_STAGED")) == 0);
-        return allow && std::is_same<R, float>::value && !iisph() && !refOrder();
+        static const int mode = getenv("NEREUS_STAGED") ? atoi(getenv("NEREUS_STAGED")) : -1;
+        if (mode == 0 || !std::is_same<R, float>::value || iisph() || refOrder() || P.numCells > (1u << 30)) return false;
+        return mode == 1 || ((cfg.flags & NRS_FLAG_FAST_ARITH) && KSET == KS_MULLER && hitBuf.p != nullptr);
     }
     // fast arithmetic (reciprocals, rsq, fused multiply-adds, density summed in the scan): fp32 Muller SESPH on the
     // production kernels with shared lists; everything else keeps the reference-order IEEE arithmetic
@@ -212,7 +241,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &hitBuf, &hitCounts, &fastQ, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &fastQ, &nearBits, &wallList, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -273,6 +302,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
                 NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
+        NRSCHK(errWord.alloc(4));
+        HIPCHK(hipMemsetAsync(errWord.p, 0, 4, stream));
         NRSCHK(redPartial.alloc(sizeof(double) * 1024));
         NRSCHK(redOut.alloc(sizeof(double)));
         // radix sort workspace for the largest problem
@@ -421,6 +452,19 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_reorder_boundary<R>), dim3(nblocks(nb)), dim3(BLOCK), 0, stream, bHashCur, bIndexCur,
                            dBi.as<T4>(), dVbi.as<R>(), bSorted.as<T4>(), bCellStart.as<uint32_t>(),
                            bCellEnd.as<uint32_t>(), (uint32_t)nb);
+        nearBitsValid = false;
+        if (!iisph() && is_pow2(P.gridSize[0]) && is_pow2(P.gridSize[1]) && is_pow2(P.gridSize[2])) {
+            const size_t words = ((size_t)P.numCells + 31) / 32;
+            NRSCHK(nearBits.alloc(words * 4));
+            const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
+            NRSCHK(wallList.alloc((size_t)cap * 4));
+            NRSCHK(wallTile.alloc(nTiles * 4)); NRSCHK(wallTileOffset.alloc(nTiles * 4));
+            NRSCHK(wallGroupTotal.alloc(nGroups * 4)); NRSCHK(wallGroupPrefix.alloc(nGroups * 4)); NRSCHK(wallScalars.alloc(16));
+            HIPCHK(hipMemsetAsync(wallScalars.p, 0, 16, stream));
+            HIPCHK(hipMemsetAsync(nearBits.p, 0, words * 4, stream));
+            hipLaunchKernelGGL((k_mark_near_boundary<R>), dim3(nblocks(nb)), dim3(BLOCK), 0, stream, P, bHashCur, (uint32_t)nb, nearBits.as<uint32_t>());
+            nearBitsValid = true;
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         t.release(); dBi.release(); dVbi.release();
@@ -434,7 +478,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         nb = nbNew;
         hostBi.assign((const T4 *)bi4, (const T4 *)bi4 + nb);
         hostVbi.assign((const R *)vbi, (const R *)vbi + nb);
-        if (!nb) return NRS_OK;
+        if (!nb) { nearBitsValid = false; return NRS_OK; }
         if (update_grid) {
             NRSCHK(invalidate_grid_state());
             // BBMin/BBMax (sph_cuda.cu:461-505) + SPH::updateGrid (sph.cpp:313-337)
@@ -523,6 +567,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         G.sB = bSorted.as<T4>();
         G.actLo = INT_MIN;
         G.actHi = INT_MAX;
+        G.nSorted = (uint32_t)n;
+        G.err = errWord.as<uint32_t>();
         return G;
     }
     IisphArrays<R> iisph_view() const
@@ -611,6 +657,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (!cellsClean) HIPCHK(hipMemsetAsync(cellStart.p, 0xff, (size_t)P.numCells * 4, stream));
         cellsClean = false;
         holesPending = false; // the gather below reads only live slots
+        wallListed = deferWalls() && !stagedScan(); // (wall workgroups read the sorted keys this stage leaves in hashCur)
         if (merged)
             hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
@@ -695,6 +742,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const bool share = !refOrder() && hitBuf.p && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         const bool fast = fastArith() && share && fastQ.p;
+        if (HAS_B && share && wallListed && !refOrder()) NRSCHK(build_wall_list(N));
+        const WallList wv = wall_view();
         bool didStaged = false;
         if constexpr (std::is_same<R, float>::value) {
             if (stagedScan()) {
@@ -703,12 +752,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 didStaged = true;
             }
         }
+        const bool wallsDeferred = !didStaged && !refOrder() && HAS_B && share && wallListed;
         if (didStaged) {
         } else if (refOrder())
             hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         else
             launch_density_tiled<R, KSET, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(), dens.as<R>(),
-                                                 presB.as<R>(), N);
+                                                 presB.as<R>(), N, (HAS_B && share && wallListed) ? &wv : (const WallList *)nullptr);
         if (slabOn) { G.actLo = slab.lo; G.actHi = slab.hi; }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_DENSITY) return NRS_OK;
@@ -758,7 +808,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             }
             if (!didFast)
                 launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
-                                                          velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N);
+                                                          velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N,
+                                                          (HAS_B && share && wallsDeferred) ? &wv : (const WallList *)nullptr);
             hashNext = fo.hash; indexNext = fo.index;
             hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
             fusedThisStep = true;
@@ -778,7 +829,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             if (!didFast)
                 launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
                                                           velB.as<T4>(), dens.as<R>(), presB.as<R>(), forces.as<T4>(),
-                                                          (const FusedOut<R> *)nullptr, N);
+                                                          (const FusedOut<R> *)nullptr, N,
+                                                          (HAS_B && share && wallsDeferred) ? &wv : (const WallList *)nullptr);
         }
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_FORCES || fuse) return NRS_OK;
@@ -1226,10 +1278,21 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (evUsed > 8192) NRSCHK(ev_collect()); // bound the pool of pending event pairs
         return NRS_OK;
     }
+    // the device-side guard (GridView::err) fired since the last check: report it, once
+    int check_device_error()
+    {
+        uint32_t e = 0;
+        HIPCHK(hipMemcpyAsync(&e, errWord.p, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (!e) return NRS_OK;
+        HIPCHK(hipMemsetAsync(errWord.p, 0, 4, stream));
+        return fail(NRS_E_STATE, "device-side consistency check failed: a cell range lies outside the sorted particle array (the cell table was "
+                                 "built from an inconsistent sort); the neighbour sweep skipped it, results of the last steps are invalid");
+    }
     int sync() override
     {
         HIPCHK(hipStreamSynchronize(stream));
-        return NRS_OK;
+        return check_device_error();
     }
     // ---- asynchronous snapshots for a viewer (include/nereus_hip.h: nrs_snapshot_*) ---------------------------
     struct Snap {
@@ -1325,7 +1388,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (vel4) HIPCHK(hipMemcpyAsync(vel4, velA.p, sizeof(T4) * n, hipMemcpyDeviceToHost, stream));
         if (pres) HIPCHK(hipMemcpyAsync(pres, presA.p, sizeof(R) * n, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        return NRS_OK;
+        return check_device_error();
     }
     int array(int which, void **dptr, uint64_t *bytes) override
     {

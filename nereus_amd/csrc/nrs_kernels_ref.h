@@ -21,7 +21,19 @@ template <typename R> struct GridView {
     // slab decomposition: a gather kernel evaluates only particles whose (unwrapped) cell-x is in [actLo, actHi)
     // and writes zeros for the rest (halo copies whose neighbourhood is incomplete on this rank)
     int actLo, actHi;
+    // consistency guard of the production scans: a fluid run [a, b) read from the cell table must lie inside the sorted array
+    // (b >= a, b <= nSorted).  A table built from a wrongly sized merge breaks that, and an unguarded sweep then walks off the
+    // allocation (the GPU memory fault of round 1); a run that fails the test is skipped and *err is set — the host reports
+    // NRS_E_STATE at the next nrs_synchronize / nrs_download instead of the device faulting.
+    uint32_t nSorted;
+    uint32_t *err;
 };
+template <typename R> NRS_DEV bool run_ok(const GridView<R> &G, uint32_t a, uint32_t b)
+{
+    const bool ok = (b >= a) & (b <= G.nSorted);
+    if (!ok && G.err) *G.err = 1u;
+    return ok;
+}
 
 template <typename R> NRS_DEV bool slab_active(const Params<R> &P, const GridView<R> &G, R x)
 {
@@ -42,6 +54,15 @@ __global__ __launch_bounds__(BLOCK) void k_hash(Params<R> P, const typename Vec4
     hash[i] = calcGridHash<R>(P, g.x, g.y, g.z);
     index[i] = i;
 }
+
+// Wall particles (see k_density_tiled, nrs_kernels_tiled.h): a sorted slot whose cell is flagged "some boundary particle in the
+// 27-neighbourhood" in this static bit table is evaluated by the wall workgroups of the gather launches.
+struct WallList {
+    const uint32_t *nearBits; // bit per cell
+    const uint32_t *hash;     // sorted keys of the step (the cell of every slot)
+    const uint32_t *list;     // this step's wall slots, ascending
+    const uint32_t *count;    // how many
+};
 
 // ---- reorderDataAndFindCellStartD (sph_kernel_impl.cuh:210-281) -------------------------------------
 // cellStart must have been filled with 0xff.  Also emits inv[index[i]] = i (needed for SURVEY Q5).

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
             const uint32_t s0 = st[r].a, s1 = st[r].b, s2 = st[r].c;
             uint32_t a = (s0 != CELL_EMPTY) ? s0 : ((s1 != CELL_EMPTY) ? s1 : s2);
             uint32_t b = (s2 != CELL_EMPTY) ? en[r].c : ((s1 != CELL_EMPTY) ? en[r].b : en[r].a);
-            if (a == CELL_EMPTY || !active) a = b = 0u;
+            if (a == CELL_EMPTY || !active || !run_ok<R>(G, a, b)) a = b = 0u;
             lo[r] = a; hi[r] = b;
             // cell number inside the run: + (j >= m1) + (j >= m2), with m1 = start of the 2nd cell or, when that one is
             // empty, of the 3rd (CELL_EMPTY = 0xffffffff compares greater than every j)

@@ -51,12 +51,6 @@ struct CutThresholds { float lenLtIr, r2LeH2; };
 #ifndef FORCES_LISTS_MIN_WAVES
 #define FORCES_LISTS_MIN_WAVES 7
 #endif
-#ifndef FORCES_COOP_LANES
-#define FORCES_COOP_LANES 4 // up to this many lanes of a wave with boundary hits: their pair terms are evaluated by the whole wave
-#endif
-#ifndef SCAN_COOP_LANES
-#define SCAN_COOP_LANES 4 // up to this many lanes of a wave with boundary cells: the wave sweeps them cooperatively
-#endif
 // value of `v` in lane `srcLane` (wave-uniform lane number), for every lane
 NRS_DEV float bcast_lane(float v, int srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane)); }
 NRS_DEV double bcast_lane(double v, int srcLane)
@@ -114,7 +108,7 @@ template <typename R> struct Sweep {
         // fluid candidates j in [a, b); the cell number advances at j == m1 and j == m2 (starts of the 2nd / 3rd
         // cell of a merged run; CELL_EMPTY when that cell is empty)
         auto sweepFluid = [&](uint32_t a, uint32_t b, uint32_t m1, uint32_t m2, uint32_t tag0) {
-            const uint32_t nT = b - a;
+            const uint32_t nT = run_ok<R>(G, a, b) ? b - a : 0u;
             for (uint32_t base = 0; base < nT; base += SCAN_BATCH) {
                 T4 c[SCAN_BATCH];
 #pragma unroll
@@ -171,53 +165,10 @@ template <typename R> struct Sweep {
             }
             if (HAS_B) {
                 anyB = anyB || bmask != 0u;
-                // Boundary cells of this plane, in ascending cell number.  A wall usually touches a wave with one or two lanes
-                // (the first particles of an x-row), each with ~20-30 boundary candidates per plane: swept lane by lane that is
-                // 6-8 rounds of global loads per plane at 2/64 lane utilisation (measured: 37 % of the density kernel's time on
-                // the dam-break).  When few lanes have boundary cells, the whole wave sweeps them for one such lane at a time —
-                // 64 candidates per round, coalesced — ranks the hits with a ballot and stores them into that lane's list:
-                // the same entries in the same order.
-                const unsigned long long wall = __ballot(bmask != 0u);
-                if (wall != 0ull && __popcll(wall) <= SCAN_COOP_LANES) {
-                    const uint32_t lane = tid & 63u, tid0 = tid & ~63u;
-                    unsigned long long todo = wall;
-                    while (todo) {
-                        const int Ln = __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        V3<R> q;
-                        q.x = bcast_lane(p.x, Ln); q.y = bcast_lane(p.y, Ln); q.z = bcast_lane(p.z, Ln);
-                        uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)bmask, Ln);
-                        const uint32_t x0L = (uint32_t)__builtin_amdgcn_readlane((int)x0, Ln), cxL = (uint32_t)__builtin_amdgcn_readlane((int)cx, Ln),
-                                       x2L = (uint32_t)__builtin_amdgcn_readlane((int)x2, Ln);
-                        const int gyL = __builtin_amdgcn_readlane(gp.y, Ln);
-                        const uint32_t planeL = (uint32_t)__builtin_amdgcn_readlane((int)plane, Ln);
-                        const int room = HIT_CAP - __builtin_amdgcn_readlane(nf, Ln); // list slots the fluid hits left
-                        int nbL = __builtin_amdgcn_readlane(nb, Ln);
-                        while (bm) {
-                            const int bit = __builtin_ctz(bm);
-                            bm &= bm - 1u;
-                            const int y = bit / 3, c = bit - y * 3;
-                            const uint32_t cyL = (uint32_t)(gyL + y - 1) & my;
-                            const uint32_t hc2 = planeL + umul24(cyL, P.gridSize[0]) + (c == 0 ? x0L : (c == 1 ? cxL : x2L));
-                            const uint32_t a = G.bCellStart[hc2], nT = G.bCellEnd[hc2] - a;
-                            const uint32_t tag = (uint32_t)((z + 1) * 9 + bit);
-                            for (uint32_t base = 0; base < nT; base += 64u) {
-                                const uint32_t qi = base + lane;
-                                const bool valid = qi < nT;
-                                const T4 cb = G.sB[a + (valid ? qi : 0u)];
-                                const V3<R> d = q - xyz<R>(cb);
-                                const bool hit = valid & (dot(d, d) < tB);
-                                const unsigned long long hm = __ballot(hit);
-                                if (hit) {
-                                    const int k = nbL + (int)__popcll(hm & ((1ull << lane) - 1ull));
-                                    if (k < room) lst[HIT_CAP - 1 - k][tid0 + (uint32_t)Ln] = (a + qi) | (tag << HIT_TAG_SHIFT);
-                                }
-                                nbL += (int)__popcll(hm);
-                            }
-                        }
-                        if (lane == (uint32_t)Ln) { nb = nbL; over = over || (nbL > room); }
-                    }
-                } else
+                // boundary cells of this plane, visited in ascending cell number by the lanes that have any
+                // (a wave-cooperative sweep — one wall lane at a time, 64 candidates per round, hits ranked with a ballot — was
+                // measured SLOWER, 0.756 vs 0.711 ms at 10 M particles: the two wall lanes of a wave already share one instruction
+                // stream, and the cooperative form pays its broadcasts and table reloads per wall lane)
                 while (bmask) {
                     const int bit = __builtin_ctz(bmask);
                     bmask &= bmask - 1u;
@@ -487,23 +438,65 @@ static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__re
 // SHARE: build the lists with the force loop's (wider) boundary cut-off and publish them for the force kernel.
 // WIDE (IISPH, Muller kernels): the published lists keep self and every candidate up to r2LeH2, for the six other
 // kernels of the IISPH chain; the density itself applies its own tests while summing.
-template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE = false>
-__global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
-                                                         const typename Vec4T<R>::type *__restrict__ sPos,
-                                                         R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
-                                                         uint32_t n)
+// Wall particles.  A fluid particle whose 27 cells hold any boundary particle pays ~50-100 extra candidates and up to HIT_CAP
+// boundary hits — and in the dam-break such particles are the first one or two of every x-row: half of all wavefronts carry
+// one or two of them and run the whole boundary machinery at 2/64 lane utilisation (measured: 37 % of the density kernel and
+// 27 % of the force kernel).  A static bit per cell ("boundary particles in the 27-neighbourhood", built once per
+// nrs_set_boundaries) tells which sorted slots these are, and each gather launch has two kinds of workgroups running the SAME
+// per-particle code:
+//   wall workgroups      (the first blocks of the grid) walk this step's WALL LIST — the wall slots in ascending order, built
+//                        after the reorder by k_wall_count / scan / k_wall_compact (ballots and a prefix sum: no atomics) —
+//                        with every lane busy, code compiled with the boundary machinery;
+//   interior workgroups  one thread per sorted slot as before, compiled WITHOUT the boundary machinery (no boundary cell-table
+//                        loads, no second list); a wall slot is skipped.
+// Each particle is still evaluated by exactly one thread with exactly the same operations: results are bit-identical.
+// (Tried first: the list appended by the reorder kernel through one atomic counter — +0.31 ms of atomic contention at 10 M
+// particles; the wall work as a launch of its own behind the interior one — a single generation of latency-bound waves that cost
+// more than it saved — or beside it on a second stream — 0.89 vs 0.65 ms, the two launches did not overlap usefully; wall
+// workgroups that each compact a fixed range of slots themselves — the floor rows make a few ranges all-wall: 0.78 ms.  The
+// one-launch form kept here allocates registers for both code paths (84 VGPRs = 5 waves/SIMD instead of 7; bounded to 72 it
+// spills: 0.68 vs 0.65 ms), which is why it recovers only part of the 37 %.)
+constexpr uint32_t COUNTS_DEFERRED = 1u << 19; // counts[]: the particle is handled by the wall workgroups
+
+NRS_DEV bool cell_near_boundary(const WallList &wl, uint32_t h) { return ((wl.nearBits[h >> 5] >> (h & 31u)) & 1u) != 0u; }
+
+// wall list, step 1: wall slots per 256-slot tile (one store per tile)
+static __global__ __launch_bounds__(BLOCK) void k_wall_count(WallList wl, uint32_t *__restrict__ tileCount, uint32_t n)
 {
-    __shared__ uint32_t lst[HIT_CAP][BLOCK];
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t tid = threadIdx.x;
-    const V3<R> p = xyz<R>(sPos[i]);
-    if (!slab_active<R>(P, G, p.x)) {
-        dens[i] = (R)0;
-        if (pres) pres[i] = (R)0;
-        if (SHARE) hb.counts[i] = 0u;
-        return;
+    __shared__ uint32_t waveCnt[BLOCK / 64];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool take = i < n && cell_near_boundary(wl, wl.hash[i]);
+    const unsigned long long m = __ballot(take);
+    if ((threadIdx.x & 63u) == 0) waveCnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) t += waveCnt[w];
+        tileCount[blockIdx.x] = t;
     }
+}
+// step 3 (step 2 is k_resort_scan_tiles over the tile counts): stable compaction of the wall slots
+static __global__ __launch_bounds__(BLOCK) void k_wall_compact(WallList wl, const uint32_t *__restrict__ tileOffset, const uint32_t *__restrict__ groupPrefix,
+                                                                 uint32_t groupSize, uint32_t *__restrict__ list, uint32_t n)
+{
+    __shared__ uint32_t waveCnt[BLOCK / 64];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool take = i < n && cell_near_boundary(wl, wl.hash[i]);
+    const unsigned long long m = __ballot(take);
+    if (lane == 0) waveCnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!take) return;
+    uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) before += waveCnt[w];
+    list[groupPrefix[blockIdx.x / groupSize] + tileOffset[blockIdx.x] + before] = i;
+}
+
+template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE>
+NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, const CutThresholds thr,
+                                    const typename Vec4T<R>::type *__restrict__ sPos, R *__restrict__ dens, R *__restrict__ pres,
+                                    const HitBuffer &hb, uint32_t i, V3<R> p, uint32_t (*lst)[BLOCK], uint32_t countFlags = 0u)
+{
+    const uint32_t tid = threadIdx.x;
     constexpr int BF = SHARE ? (KSET == KS_MULLER ? 1 : 2) : 0;
     const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK, WIDE>(P, G, thr, sPos, WIDE ? 0xffffffffu : i, p, lst);
     R d;
@@ -512,12 +505,53 @@ __global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
     if (SHARE) {
-        hb.counts[i] = pack_counts(hc);
+        hb.counts[i] = pack_counts(hc) | countFlags;
         if (!hc.over) {
             for (int k = 0; k < hc.nf; ++k) hb.hits[(size_t)k * hb.stride + i] = lst[k][tid];
             for (int k = 0; k < hc.nb; ++k) hb.hits[(size_t)(HIT_CAP - 1 - k) * hb.stride + i] = lst[HIT_CAP - 1 - k][tid];
         }
     }
+}
+
+// DEFER (only with boundaries and shared lists): the two kinds of workgroups described above; HAS_B is then false for the
+// interior code, and the first `wallBlocks` blocks of the grid walk the wall list with the boundary code.
+template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE = false, bool DEFER = false>
+__global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
+                                                         const typename Vec4T<R>::type *__restrict__ sPos,
+                                                         R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
+                                                         uint32_t n, WallList wl, uint32_t wallBlocks)
+{
+    __shared__ uint32_t lst[HIT_CAP][BLOCK];
+    uint32_t block = blockIdx.x, blocks = gridDim.x;
+    if (DEFER) {
+        if (block < wallBlocks) {
+            const uint32_t count = *wl.count;
+            for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK) {
+                const uint32_t i = wl.list[t];
+                const V3<R> p = xyz<R>(sPos[i]);
+                if (!slab_active<R>(P, G, p.x)) {
+                    dens[i] = (R)0;
+                    if (pres) pres[i] = (R)0;
+                    hb.counts[i] = COUNTS_DEFERRED;
+                    continue;
+                }
+                density_tiled_particle<R, KSET, true, SHARE, WIDE>(P, G, thr, sPos, dens, pres, hb, i, p, lst, COUNTS_DEFERRED);
+            }
+            return;
+        }
+        block -= wallBlocks; blocks -= wallBlocks;
+    }
+    const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (DEFER && cell_near_boundary(wl, wl.hash[i])) return; // a wall slot
+    const V3<R> p = xyz<R>(sPos[i]);
+    if (!slab_active<R>(P, G, p.x)) {
+        dens[i] = (R)0;
+        if (pres) pres[i] = (R)0;
+        if (SHARE) hb.counts[i] = 0u;
+        return;
+    }
+    density_tiled_particle<R, KSET, HAS_B, SHARE, WIDE>(P, G, thr, sPos, dens, pres, hb, i, p, lst);
 }
 
 // ---- forces (computeForces, sph_kernel_impl.cuh:609-680).  FUSE: the same launch also integrates
@@ -610,67 +644,76 @@ __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R>
 // scan-free form: consumes the hit lists the density kernel of the same step published (no LDS ⇒ occupancy is
 // bounded by registers only)
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE>
+NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, const HitBuffer &hb,
+                                   const typename Vec4T<R>::type *__restrict__ sPos, const typename Vec4T<R>::type *__restrict__ sVel,
+                                   const R *__restrict__ sDens, const R *__restrict__ sPres, typename Vec4T<R>::type *__restrict__ forces,
+                                   const FusedOut<R> &fo, uint32_t i, typename Vec4T<R>::type p4, typename Vec4T<R>::type v4,
+                                   bool active, HitCounts hc)
+{
+    const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
+    V3<R> f = mk3<R>(0, 0, 0);
+    if (active) {
+        const R dens = sDens[i], pres = sPres[i];
+        ForceAcc<R> A;
+        if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc);
+        f = sesph_total_force<R>(P, A, dens);
+    }
+    forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
+}
+
+// DEFER: wall workgroups first, interior workgroups skip the particles flagged COUNTS_DEFERRED (see k_density_tiled); HAS_B is
+// false for the interior code
+template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE, bool DEFER = false>
 __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? FORCES_LISTS_MIN_WAVES : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const typename Vec4T<R>::type *__restrict__ sVel,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,
                                                         typename Vec4T<R>::type *__restrict__ forces, FusedOut<R> fo,
-                                                        uint32_t n)
+                                                        uint32_t n, WallList wl, uint32_t wallBlocks)
 {
     typedef typename Vec4T<R>::type T4;
-    // Boundary hits belong to the one or two lanes of a wave that sit at a wall (up to HIT_CAP each, ~250 instructions per hit
-    // with the reference's divisions): when few lanes have any, their pair terms are evaluated by the whole wave first — lane t
-    // takes hit t — and parked in LDS; the owner then adds them in the reference's order while it walks its lists.
-    __shared__ R bterm[HAS_B ? BLOCK / 64 : 1][HAS_B ? FORCES_COOP_LANES : 1][HAS_B ? HIT_CAP : 1][9];
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const T4 p4 = sPos[i];
-    const T4 v4 = sVel[i];
-    const V3<R> pos1 = xyz<R>(p4), vel1 = xyz<R>(v4);
-    V3<R> f = mk3<R>(0, 0, 0);
-    const bool active = slab_active<R>(P, G, pos1.x);
-    R dens = (R)0, pres = (R)0;
-    HitCounts hc;
-    hc.nf = 0; hc.nb = 0; hc.over = false; hc.anyB = false;
-    if (active) { dens = sDens[i]; pres = sPres[i]; hc = unpack_counts(hb.counts[i]); }
-    const R *pre = nullptr;
-    if (HAS_B) {
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const int nbMine = (active && !hc.over) ? hc.nb : 0;
-        const unsigned long long wall = __ballot(nbMine > 0);
-        if (wall != 0ull && __popcll(wall) <= FORCES_COOP_LANES) {
-            unsigned long long todo = wall;
-            int s = 0;
-            while (todo) {
-                const int Ln = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const int nbL = __builtin_amdgcn_readlane(nbMine, Ln);
-                const uint32_t iL = (uint32_t)__builtin_amdgcn_readlane((int)i, Ln);
-                V3<R> pl, vl;
-                pl.x = bcast_lane(pos1.x, Ln); pl.y = bcast_lane(pos1.y, Ln); pl.z = bcast_lane(pos1.z, Ln);
-                vl.x = bcast_lane(vel1.x, Ln); vl.y = bcast_lane(vel1.y, Ln); vl.z = bcast_lane(vel1.z, Ln);
-                const R dl = bcast_lane(dens, Ln), prl = bcast_lane(pres, Ln);
-                if ((int)lane < nbL) { // nbL <= HIT_CAP < 64: one round; hit t of the owner = list slot HIT_CAP-1-t
-                    const uint32_t j = hb.hits[(size_t)(HIT_CAP - 1 - (int)lane) * hb.stride + iL] & HIT_INDEX;
-                    const BoundaryTerms<R, KSET> T = boundary_terms<R, KSET>(P, pl, vl, dl, prl, G.sB[j]);
-                    R *t = &bterm[wave][s][lane][0];
-                    t[0] = T.bound.x; t[1] = T.bound.y; t[2] = T.bound.z;
-                    t[3] = T.pres.x; t[4] = T.pres.y; t[5] = T.pres.z;
-                    t[6] = T.visc.x; t[7] = T.visc.y; t[8] = T.visc.z;
-                }
-                if (lane == (uint32_t)Ln) pre = &bterm[wave][s][0][0];
-                ++s;
+    uint32_t block = blockIdx.x, blocks = gridDim.x;
+    if (DEFER) {
+        if (block < wallBlocks) {
+            const uint32_t count = *wl.count;
+            for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK) {
+                const uint32_t i = wl.list[t];
+                const T4 p4 = sPos[i];
+                const bool active = slab_active<R>(P, G, p4.x);
+                forces_lists_particle<R, KSET, SURF, true, FUSE>(P, G, hb, sPos, sVel, sDens, sPres, forces, fo, i, p4, sVel[i], active,
+                                                                 unpack_counts(active ? hb.counts[i] : 0u));
             }
+            return;
         }
+        block -= wallBlocks; blocks -= wallBlocks;
     }
-    if (active) {
-        ForceAcc<R> A;
-        if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc,
-                                                        0xffffffffu, pre);
-        f = sesph_total_force<R>(P, A, dens);
-    }
-    forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
+    const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = hb.counts[i];
+    if (DEFER && (c & COUNTS_DEFERRED)) return;
+    const T4 p4 = sPos[i];
+    const bool active = slab_active<R>(P, G, p4.x);
+    forces_lists_particle<R, KSET, SURF, HAS_B, FUSE>(P, G, hb, sPos, sVel, sDens, sPres, forces, fo, i, p4, sVel[i], active,
+                                                      unpack_counts(active ? c : 0u));
+}
+
+// marks, for every cell that holds boundary particles, the 27 cells around it (power-of-two grids: the reference's wrap)
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_mark_near_boundary(Params<R> P, const uint32_t *__restrict__ bHash, uint32_t nb, uint32_t *__restrict__ nearBits)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nb) return;
+    const uint32_t h = bHash[i];
+    if (i && bHash[i - 1] == h) return; // one thread per occupied cell
+    const uint32_t gx = P.gridSize[0], gy = P.gridSize[1];
+    const int x = (int)(h & (gx - 1)), y = (int)((h / gx) & (gy - 1)), z = (int)(h / (gx * gy));
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const uint32_t c = calcGridHash<R>(P, x + dx, y + dy, z + dz);
+                atomicOr(&nearBits[c >> 5], 1u << (c & 31u));
+            }
 }
 
 static inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
@@ -698,20 +741,31 @@ template <typename R> static inline CutThresholds make_thresholds(const Params<R
     return t;
 }
 
+// wall workgroups of a gather launch (grid-stride over the wall list, whose length is only known on the device)
+static inline uint32_t wall_blocks(uint32_t interiorBlocks) { return std::min<uint32_t>(1024u, std::max<uint32_t>(1u, interiorBlocks / 16u)); }
+
+// wall: this step's wall list (k_wall_count / scan / k_wall_compact) — needs `share`; null = one kind of workgroup
 template <typename R, int KSET, bool HAS_B>
 static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer *share,
-                                        const typename Vec4T<R>::type *sPos, R *dens, R *pres, uint32_t n)
+                                        const typename Vec4T<R>::type *sPos, R *dens, R *pres, uint32_t n, const WallList *wall = nullptr)
 {
     const CutThresholds thr = make_thresholds<R>(P);
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     HitBuffer hb = {nullptr, nullptr, 0};
+    const WallList none = {nullptr, nullptr, nullptr, nullptr};
     // occupancy experiment: extra dynamic LDS per workgroup lowers the workgroups per CU
     static const unsigned pad = getenv("NEREUS_DBG_LDS_PAD") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD")) : 0u;
     if (share) {
         hb = *share;
-        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true>), g, b, pad, stream, P, G, thr, sPos, dens, pres, hb, n);
+        if (HAS_B && wall) {
+            const uint32_t wb = wall_blocks(g.x);
+            hipLaunchKernelGGL((k_density_tiled<R, KSET, false, true, false, true>), dim3(g.x + wb), b, pad, stream, P, G, thr, sPos, dens, pres, hb, n,
+                               *wall, wb);
+        } else {
+            hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true>), g, b, pad, stream, P, G, thr, sPos, dens, pres, hb, n, none, 0u);
+        }
     } else {
-        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n);
+        hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, false>), g, b, 0, stream, P, G, thr, sPos, dens, pres, hb, n, none, 0u);
     }
 }
 template <typename R, int KSET, bool HAS_B>
@@ -719,14 +773,16 @@ static inline void launch_density_wide(hipStream_t stream, const Params<R> &P, c
                                        const typename Vec4T<R>::type *sPos, R *dens, uint32_t n)
 {
     const CutThresholds thr = make_thresholds<R>(P);
+    const WallList none = {nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true, true>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr,
-                       sPos, dens, (R *)nullptr, hb, n);
+                       sPos, dens, (R *)nullptr, hb, n, none, 0u);
 }
 // `lists`: hit lists published by launch_density_tiled of the same step (then no scan), or nullptr
 template <typename R, int KSET, bool SURF, bool HAS_B>
 static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer *lists,
                                        const typename Vec4T<R>::type *sPos, const typename Vec4T<R>::type *sVel, const R *dens,
-                                       const R *pres, typename Vec4T<R>::type *forces, const FusedOut<R> *fused, uint32_t n)
+                                       const R *pres, typename Vec4T<R>::type *forces, const FusedOut<R> *fused, uint32_t n,
+                                       const WallList *wall = nullptr)
 {
     FusedOut<R> fo;
     fo.newPos = fo.newVel = nullptr;
@@ -741,9 +797,15 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     static const unsigned padF = getenv("NEREUS_DBG_LDS_PAD_F") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD_F")) : 0u; // occupancy experiment
-    if (lists) {
-        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, true>), g, b, padF, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
-        else hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n);
+    const WallList none = {nullptr, nullptr, nullptr, nullptr};
+    if (lists && HAS_B && wall) { // wall workgroups + interior workgroups without the boundary code (see k_density_tiled)
+        const uint32_t wb = wall_blocks(g.x);
+        const dim3 gd(g.x + wb);
+        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, false, true, true>), gd, b, padF, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n, *wall, wb);
+        else hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, false, false, true>), gd, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n, *wall, wb);
+    } else if (lists) {
+        if (fused) hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, true>), g, b, padF, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n, none, 0u);
+        else hipLaunchKernelGGL((k_forces_lists<R, KSET, SURF, HAS_B, false>), g, b, 0, stream, P, G, *lists, sPos, sVel, dens, pres, forces, fo, n, none, 0u);
     } else {
         const CutThresholds thr = make_thresholds<R>(P);
         if (fused) hipLaunchKernelGGL((k_forces_tiled<R, KSET, SURF, HAS_B, true>), g, b, 0, stream, P, G, thr, sPos, sVel, dens, pres, forces, fo, n);

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Developed-flow profile of the bench workload: the dam has broken by step ~700 (tools/regime_probe.py).  Kernel trace over a run
+# of 800 steps (tools/summarize_profile.py ... 100 keeps the last 100), HBM counters over runs of 705 steps (last 5 kept).
+# usage (GPU box, via gpurun): bash tools/profile_developed.sh <tag> [bench args]
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${1:-x}; shift
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 100 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+echo "trace done" >> $OUT/progress.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/fetch.log 2>&1
+echo "fetch done" >> $OUT/progress.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/write.log 2>&1
+echo "write done" >> $OUT/progress.log

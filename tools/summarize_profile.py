@@ -10,7 +10,8 @@ import shutil
 import sys
 from collections import defaultdict
 
-SHORT = [("k_density_tiled", "k_density_tiled"), ("k_forces_lists", "k_forces_lists"), ("k_forces_tiled", "k_forces_tiled"),
+SHORT = [("k_density_staged", "k_density_staged"), ("k_forces_fast", "k_forces_fast"), ("k_wall_count", "k_wall_count"),
+         ("k_wall_compact", "k_wall_compact"), ("k_density_tiled", "k_density_tiled"), ("k_forces_lists", "k_forces_lists"), ("k_forces_tiled", "k_forces_tiled"),
          ("k_reorder_merged", "k_reorder_merged"), ("k_reorder_boundary", "k_reorder_boundary"), ("k_reorder", "k_reorder"),
          ("k_clear_cells", "k_clear_cells"), ("k_hash", "k_hash"), ("k_resort_split", "k_resort_split"),
          ("k_resort_scan_tiles", "k_resort_scan_tiles"), ("k_resort_count", "k_resort_count"), ("k_integrate", "k_integrate"),
@@ -26,20 +27,49 @@ def short(name):
     return name[:60]
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, last=0):
+    """counter values per kernel, in dispatch order; last > 0 keeps only the last `last` dispatches of each kernel"""
     acc = defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    for r in rows:
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    if last:
+        acc = {k: v[-last:] for k, v in acc.items()}
+    return acc
+
+
+def tail_stats(trace_csv, dst_csv, steps):
+    """per-kernel launch statistics over the LAST `steps` steps of a kernel trace (a step = one k_forces_* launch)"""
+    rows = list(csv.DictReader(open(trace_csv)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if "k_forces_" in r["Kernel_Name"]]
+    t0 = marks[-steps] if len(marks) >= steps else marks[0]
+    first_stage = min((int(r["Start_Timestamp"]) for r in rows if int(r["Start_Timestamp"]) >= t0), default=t0)
+    acc = defaultdict(list)
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= first_stage:
+            acc[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in acc.values())
+    with open(dst_csv, "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","CallsPerStep"\n')
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            f.write('"%s",%d,%d,%.1f,%.2f,%.2f\n' % (k, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / total, len(v) / float(steps)))
     return acc
 
 
 def main():
+    """usage: summarize_profile.py <prof dir> <name> "<workload>" <particles> [tail steps]
+    with `tail steps` the statistics cover only the last so-many steps of the traced run (developed-flow profiles)"""
     src, name, workload, particles = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    tail = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(root, name + "_kernel_stats.csv"))
-    f = per_kernel(os.path.join(src, "fetch", "f_counter_collection.csv"), "FETCH_SIZE")
-    w = per_kernel(os.path.join(src, "write", "w_counter_collection.csv"), "WRITE_SIZE")
+    if tail:
+        tail_stats(os.path.join(src, "trace", "t_kernel_trace.csv"), os.path.join(root, name + "_kernel_stats.csv"), tail)
+    else:
+        shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(root, name + "_kernel_stats.csv"))
+    f = per_kernel(os.path.join(src, "fetch", "f_counter_collection.csv"), "FETCH_SIZE", 5 if tail else 0)
+    w = per_kernel(os.path.join(src, "write", "w_counter_collection.csv"), "WRITE_SIZE", 5 if tail else 0)
     out = {"workload": workload,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter values are KB per dispatch; "
                    "corrected = 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
