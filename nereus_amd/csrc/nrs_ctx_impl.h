@@ -64,7 +64,24 @@ static uint32_t next_pow2(uint32_t v) // sph/sph.cpp:300-311
 
 template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     typedef typename Vec4T<R>::type T4;
-    Params<R> P;
+    // PU: the parameters as the caller set them (GLOBAL grid; what nrs_get_params returns).  P: what the kernels get — PU
+    // with numBodies = first column of the cell-table window (0 = whole grid) and, for a slab rank, gridSize[0] / numCells of
+    // that window: a rank keeps cell tables only for its own cell-x columns + halo, so table memory (and the radix-sort key
+    // width) stop growing with the number of ranks.  Cell coordinates stay global (calcGridPos is unchanged), only the hash
+    // rebases x: the sort order, and with it every per-particle result, is the one of the global grid.
+    Params<R> PU, P;
+    int winBase = 0;
+    uint32_t winW = 0; // 0: no window
+    void derive_kernel_params()
+    {
+        P = PU;
+        P.numBodies = 0;
+        if (winW && winW < PU.gridSize[0]) {
+            P.numBodies = (uint32_t)winBase;
+            P.gridSize[0] = winW;
+            P.numCells = winW * PU.gridSize[1] * PU.gridSize[2];
+        }
+    }
     nrs_config cfg;
     uint64_t cap = 0, n = 0, nb = 0;
     bool midStep = false; // a partial step left the state mid-update
@@ -94,12 +111,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return allow && nearBitsValid && nb != 0 && !iisph() && !refOrder() && hitBuf.p != nullptr;
     }
     WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1}; }
-    // this step's wall list from the sorted keys: tile counts -> two-level scan (the re-sort's scan kernel) -> stable compaction
+    // this step's wall list: tile counts (reorder kernel) -> two-level scan (the re-sort's scan kernel) -> stable compaction
     int build_wall_list(uint32_t N)
     {
         const uint32_t nTiles = nblocks(N), nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
-        const WallList wl = wall_view();
-        hipLaunchKernelGGL(k_wall_count, dim3(nTiles), dim3(BLOCK), 0, stream, wl, wallTile.as<uint32_t>(), N);
+        const WallList wl = wall_view(); // (the tile counts were left by the reorder kernel of this step)
         uint32_t *sc = wallScalars.as<uint32_t>();
         const ResortScan a = {wallTile.as<uint32_t>(), wallTileOffset.as<uint32_t>(), wallGroupTotal.as<uint32_t>(), wallGroupPrefix.as<uint32_t>(), sc + 1};
         const ResortScan none = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -277,7 +293,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         cfg = c;
         cap = c.capacity;
         if (cap == 0 || cap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "capacity must be in 1..2^27-1");
-        std::memcpy(&P, params, sizeof(P));
+        std::memcpy(&PU, params, sizeof(PU));
+        derive_kernel_params();
         const size_t v = sizeof(T4) * cap, s = sizeof(R) * cap, u = 4 * cap;
         NRSCHK(posA.alloc(v)); NRSCHK(posB.alloc(v)); NRSCHK(velA.alloc(v)); NRSCHK(velB.alloc(v));
         NRSCHK(presA.alloc(s)); NRSCHK(presB.alloc(s)); NRSCHK(dens.alloc(s)); NRSCHK(forces.alloc(v));
@@ -354,14 +371,17 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         Params<R> q;
         std::memcpy(&q, params, sizeof(q));
-        const bool regrid = q.numCells != P.numCells;
         // the keys the fused force kernel left for the next step depend on the grid only (a new time step or viscosity
         // does not invalidate them: the reference calls setParameters every update(), the CFL variant with a new dt)
-        const bool sameGrid = std::memcmp(P.gridSize, q.gridSize, sizeof(P.gridSize)) == 0 && q.numCells == P.numCells &&
-                              std::memcmp(P.worldOrigin, q.worldOrigin, sizeof(P.worldOrigin)) == 0 &&
-                              std::memcmp(P.cellSize, q.cellSize, sizeof(P.cellSize)) == 0;
+        const bool sameGrid = std::memcmp(PU.gridSize, q.gridSize, sizeof(PU.gridSize)) == 0 && q.numCells == PU.numCells &&
+                              std::memcmp(PU.worldOrigin, q.worldOrigin, sizeof(PU.worldOrigin)) == 0 &&
+                              std::memcmp(PU.cellSize, q.cellSize, sizeof(PU.cellSize)) == 0;
         if (!sameGrid) NRSCHK(invalidate_grid_state());
-        P = q;
+        const uint32_t cellsBefore = P.numCells;
+        PU = q;
+        if (!sameGrid && slabOn) choose_window(slab.lo, slab.hi, slab.halo, true);
+        derive_kernel_params();
+        const bool regrid = P.numCells != cellsBefore;
         if (regrid) NRSCHK(alloc_cells());
         if (!sameGrid && nb) NRSCHK(rebuild_boundary_tables()); // the boundary hashes / cell table depend on origin, cell size and extents
         return NRS_OK;
@@ -378,7 +398,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     }
     int get_params(void *params) override
     {
-        std::memcpy(params, &P, sizeof(P));
+        std::memcpy(params, &PU, sizeof(PU));
         return NRS_OK;
     }
 
@@ -492,14 +512,16 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             }
             uint32_t g[3];
             for (int a = 0; a < 3; ++a) {
-                P.worldOrigin[a] = (R)(mn[a] - 0.1);
-                const uint32_t sz = (uint32_t)std::ceil((mx[a] - mn[a] + 0.1) / P.interactionRadius);
+                PU.worldOrigin[a] = (R)(mn[a] - 0.1);
+                const uint32_t sz = (uint32_t)std::ceil((mx[a] - mn[a] + 0.1) / PU.interactionRadius);
                 g[a] = next_pow2(sz);
             }
             const uint64_t C = (uint64_t)g[0] * g[1] * g[2];
             if (C > (1ull << 31)) return fail(NRS_E_INVALID, "grid from boundary AABB exceeds 2^31 cells");
-            P.gridSize[0] = g[0]; P.gridSize[1] = g[1]; P.gridSize[2] = g[2];
-            P.numCells = (uint32_t)C;
+            PU.gridSize[0] = g[0]; PU.gridSize[1] = g[1]; PU.gridSize[2] = g[2];
+            PU.numCells = (uint32_t)C;
+            if (slabOn) choose_window(slab.lo, slab.hi, slab.halo, true);
+            derive_kernel_params();
         }
         return rebuild_boundary_tables();
     }
@@ -661,11 +683,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (merged)
             hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
-                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
+                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>());
         else
             hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
-                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N);
+                               cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>());
         NRSCHK(ev_end());
         return NRS_OK;
     }
@@ -975,7 +999,40 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         slab.lo = lo; slab.hi = hi; slab.halo = halo;
         slabOn = true;
         nOwned = n;
+        // cell-table window of this rank (see PU / P): re-chosen only when the slab no longer fits the current one
+        const uint32_t cellsBefore = P.numCells, baseBefore = P.numBodies;
+        if (choose_window(lo, hi, halo, false)) {
+            NRSCHK(invalidate_grid_state());
+            derive_kernel_params();
+            if (P.numCells != cellsBefore || P.numBodies != baseBefore) {
+                cellsAllocated = 0; // (same size, other columns: the tables still have to be reset)
+                NRSCHK(alloc_cells());
+                if (nb) NRSCHK(rebuild_boundary_tables());
+            }
+        }
         return NRS_OK;
+    }
+    // Window [winBase, winBase + winW) of cell-x columns covering the slab, its halo, two columns of drift and WINDOW_SLACK columns
+    // of room for moving cuts; returns true when it changed.  force: choose afresh (the global grid changed).
+    static constexpr int WINDOW_SLACK = 8;
+    bool choose_window(int lo, int hi, int halo, bool force)
+    {
+        static const bool allow = !(getenv("NEREUS_SLAB_LOCAL_GRID") && atoi(getenv("NEREUS_SLAB_LOCAL_GRID")) == 0);
+        const long long GX = (long long)PU.gridSize[0];
+        const bool pow2 = is_pow2(PU.gridSize[0]) && is_pow2(PU.gridSize[1]) && is_pow2(PU.gridSize[2]);
+        long long a = std::max<long long>(0, (long long)lo - halo - 2), b = std::min<long long>(GX, (long long)hi + halo + 2);
+        if (!allow || !pow2 || b <= a) {
+            const bool changed = winW != 0;
+            winW = 0; winBase = 0;
+            return changed;
+        }
+        if (!force && winW && a >= winBase && b <= (long long)winBase + (long long)winW) return false; // still fits
+        a = std::max<long long>(0, a - WINDOW_SLACK); b = std::min<long long>(GX, b + WINDOW_SLACK);
+        const uint32_t w = next_pow2((uint32_t)(b - a));
+        const int baseOld = winBase; const uint32_t wOld = winW;
+        if (w >= (uint32_t)GX) { winW = 0; winBase = 0; }
+        else { winW = w; winBase = (int)a; }
+        return winW != wOld || winBase != baseOld;
     }
     uint64_t num_owned() override { return slabOn ? nOwned : n; }
     int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) override

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
 
     const I3 gp = calcGridPos<R>(P, p);
     const uint32_t mx = P.gridSize[0] - 1, my = P.gridSize[1] - 1, mz = P.gridSize[2] - 1;
-    const uint32_t cx = (uint32_t)gp.x & mx, cy = (uint32_t)gp.y & my, cz = (uint32_t)gp.z & mz;
+    const uint32_t cx = grid_x<R>(P, gp.x), cy = (uint32_t)gp.y & my, cz = (uint32_t)gp.z & mz;
     const bool edge = active && (cx == 0u || cx == mx || cy == 0u || cy == my || cz == 0u || cz == mz);
     constexpr int BF = SHARE ? (KSET == KS_MULLER ? 1 : 2) : 0;
 

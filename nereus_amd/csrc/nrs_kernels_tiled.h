@@ -96,7 +96,7 @@ template <typename R> struct Sweep {
     {
         const I3 gp = calcGridPos<R>(P, p);
         const uint32_t mx = P.gridSize[0] - 1, my = P.gridSize[1] - 1, mz = P.gridSize[2] - 1;
-        const uint32_t cx = (uint32_t)gp.x & mx;
+        const uint32_t cx = grid_x<R>(P, gp.x);
         const uint32_t x0 = (cx - 1u) & mx, x2 = (cx + 1u) & mx;
         const bool contiguous = (cx >= 1u) && (cx + 1u <= mx);
         const float tF = FWIDE ? thr.r2LeH2 : thr.lenLtIr;
@@ -445,7 +445,7 @@ static __global__ __launch_bounds__(BLOCK) void k_hit_stats(const uint32_t *__re
 // nrs_set_boundaries) tells which sorted slots these are, and each gather launch has two kinds of workgroups running the SAME
 // per-particle code:
 //   wall workgroups      (the first blocks of the grid) walk this step's WALL LIST — the wall slots in ascending order, built
-//                        after the reorder by k_wall_count / scan / k_wall_compact (ballots and a prefix sum: no atomics) —
+//                        by the reorder kernel (per-tile counts), a prefix sum and k_wall_compact (ballots: no atomics) —
 //                        with every lane busy, code compiled with the boundary machinery;
 //   interior workgroups  one thread per sorted slot as before, compiled WITHOUT the boundary machinery (no boundary cell-table
 //                        loads, no second list); a wall slot is skipped.
@@ -460,21 +460,7 @@ constexpr uint32_t COUNTS_DEFERRED = 1u << 19; // counts[]: the particle is hand
 
 NRS_DEV bool cell_near_boundary(const WallList &wl, uint32_t h) { return ((wl.nearBits[h >> 5] >> (h & 31u)) & 1u) != 0u; }
 
-// wall list, step 1: wall slots per 256-slot tile (one store per tile)
-static __global__ __launch_bounds__(BLOCK) void k_wall_count(WallList wl, uint32_t *__restrict__ tileCount, uint32_t n)
-{
-    __shared__ uint32_t waveCnt[BLOCK / 64];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool take = i < n && cell_near_boundary(wl, wl.hash[i]);
-    const unsigned long long m = __ballot(take);
-    if ((threadIdx.x & 63u) == 0) waveCnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) t += waveCnt[w];
-        tileCount[blockIdx.x] = t;
-    }
-}
+// wall list: step 1 (wall slots per 256-slot tile) rides in the reorder kernels (wall_tile_count, nrs_kernels_ref.h),
 // step 3 (step 2 is k_resort_scan_tiles over the tile counts): stable compaction of the wall slots
 static __global__ __launch_bounds__(BLOCK) void k_wall_compact(WallList wl, const uint32_t *__restrict__ tileOffset, const uint32_t *__restrict__ groupPrefix,
                                                                  uint32_t groupSize, uint32_t *__restrict__ list, uint32_t n)
@@ -515,8 +501,11 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
 
 // DEFER (only with boundaries and shared lists): the two kinds of workgroups described above; HAS_B is then false for the
 // interior code, and the first `wallBlocks` blocks of the grid walk the wall list with the boundary code.
+#ifndef DENSITY_DEFER_MIN_WAVES
+#define DENSITY_DEFER_MIN_WAVES 6 // waves/SIMD the two-kinds-of-workgroups kernel is register-bounded for: unbounded 84 VGPRs (5 waves) 0.677 ms, 6 (80 VGPRs, 3 dwords spilled) 0.650, 7 (72, 11 spilled) 0.651
+#endif
 template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE = false, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
+__global__ __launch_bounds__(BLOCK, ((DEFER && sizeof(R) == 4) ? DENSITY_DEFER_MIN_WAVES : 1)) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                          const typename Vec4T<R>::type *__restrict__ sPos,
                                                          R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
                                                          uint32_t n, WallList wl, uint32_t wallBlocks)
@@ -707,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) void k_mark_near_boundary(Params<R> P, const
     const uint32_t h = bHash[i];
     if (i && bHash[i - 1] == h) return; // one thread per occupied cell
     const uint32_t gx = P.gridSize[0], gy = P.gridSize[1];
-    const int x = (int)(h & (gx - 1)), y = (int)((h / gx) & (gy - 1)), z = (int)(h / (gx * gy));
+    const int x = (int)((h & (gx - 1)) + P.numBodies), y = (int)((h / gx) & (gy - 1)), z = (int)(h / (gx * gy)); // (x: global column)
     for (int dz = -1; dz <= 1; ++dz)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
@@ -744,7 +733,7 @@ template <typename R> static inline CutThresholds make_thresholds(const Params<R
 // wall workgroups of a gather launch (grid-stride over the wall list, whose length is only known on the device)
 static inline uint32_t wall_blocks(uint32_t interiorBlocks) { return std::min<uint32_t>(1024u, std::max<uint32_t>(1u, interiorBlocks / 16u)); }
 
-// wall: this step's wall list (k_wall_count / scan / k_wall_compact) — needs `share`; null = one kind of workgroup
+// wall: this step's wall list (tile counts of the reorder kernel / scan / k_wall_compact) — needs `share`; null = one kind of workgroup
 template <typename R, int KSET, bool HAS_B>
 static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer *share,
                                         const typename Vec4T<R>::type *sPos, R *dens, R *pres, uint32_t n, const WallList *wall = nullptr)

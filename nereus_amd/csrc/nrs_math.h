@@ -164,10 +164,14 @@ template <typename R> NRS_DEV I3 calcGridPos(const Params<R> &P, V3<R> p)
     return g;
 }
 NRS_DEV uint32_t umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
-// calcGridHash (:118-125): power-of-two wrap, 24-bit multiplies
+// calcGridHash (:118-125): power-of-two wrap, 24-bit multiplies.
+// P.numBodies (unused by the reference, common/sph_kernel.cuh:27) carries the first cell-x column of the context's cell-table
+// WINDOW in the device-side copy of the parameters: 0 for a single domain (then this is the reference's hash exactly); a slab
+// rank keeps tables only for its own columns + halo, gridSize[0] being the (power-of-two) window width (nrs_ctx_impl.h).
+template <typename R> NRS_DEV uint32_t grid_x(const Params<R> &P, int gx) { return ((uint32_t)gx - P.numBodies) & (P.gridSize[0] - 1); }
 template <typename R> NRS_DEV uint32_t calcGridHash(const Params<R> &P, int gx, int gy, int gz)
 {
-    uint32_t x = (uint32_t)gx & (P.gridSize[0] - 1);
+    uint32_t x = grid_x<R>(P, gx);
     uint32_t y = (uint32_t)gy & (P.gridSize[1] - 1);
     uint32_t z = (uint32_t)gz & (P.gridSize[2] - 1);
     return umul24(umul24(z, P.gridSize[1]), P.gridSize[0]) + umul24(y, P.gridSize[0]) + x;

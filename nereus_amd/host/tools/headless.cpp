@@ -65,8 +65,8 @@ int main(int argc, char **argv)
         std::fclose(o);
         return 0;
     }
-    const bool iisph = kind == "iisph";
-    Nereus::SPH *sim = iisph ? (Nereus::SPH *)new Nereus::IISPH() : new Nereus::SPH();
+    const bool iisph = kind == "iisph", pcisph = kind == "pcisph";
+    Nereus::SPH *sim = iisph ? (Nereus::SPH *)new Nereus::IISPH() : (pcisph ? (Nereus::SPH *)new Nereus::PCISPH() : new Nereus::SPH());
     sim->_initialize();
     std::vector<SVec4> bi;
     std::vector<SReal> vbi;

@@ -87,6 +87,31 @@ def test_class_api_run_matches_oracle(tmp_path, hip_lib, kind, solver):
 
 
 @pytest.mark.gpu
+def test_pcisph_class_mirrors_the_reference_stub(tmp_path, hip_lib):
+    """Nereus::PCISPH::update() in the reference (sph/pcisph/pcisph.cpp:161-204) builds the grid, evaluates density / Tait
+    pressure, runs an EMPTY pressure solve and copies the SORTED arrays back: nothing moves, the host arrays come back in hash
+    order.  Same here: positions / velocities equal the oracle's sorted arrays bit for bit, pressures to 1 ulp of powf; a
+    second update() is idempotent."""
+    from tests.oracle_lib import STOP_DENSITY
+
+    p, sc = small_dam_break()
+    pos, vel, bi, vbi = sc["pos"], sc["vel"].copy(), sc["bi"], sc["vbi"]
+    vel[:, 0] = 0.25  # velocities must travel with their particles through the sort
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_in(fin, pos, vel, bi, vbi)
+    o = Oracle(p, solver=SESPH)
+    o.set_particles(pos, vel)
+    o.set_boundaries(bi, vbi, update_grid=True)
+    o.step(1, stop=STOP_DENSITY)
+    for steps in (1, 2):
+        subprocess.check_call([_driver(), "run", "pcisph", fin, str(steps), fout], stdout=subprocess.DEVNULL)
+        got = _read_out(fout)
+        np.testing.assert_array_equal(got["pos"], o.get("sortedPos"))
+        np.testing.assert_array_equal(got["vel"], o.get("sortedVel"))
+        assert rel_err(got["pressure"], o.get("pres")) <= 2e-6
+
+
+@pytest.mark.gpu
 def test_main_cpp_scene_through_class_api(tmp_path, hip_lib):
     """main.cpp:533-553 — IISPH(), generateParticleCube, sampleBox/getVbi, updateGpuBoundaries, update()."""
     fout = str(tmp_path / "out.bin")
