@@ -184,6 +184,17 @@ def developed_record(s, capi, n, skip, steps, steps_before, bpp, real_bytes, tor
         "fell_back_to_full_sort": fb1 - fb0,
     }
     try:
+        vmax = s.max_velocity()
+        P = s.params
+        h, dtp, cs = float(P["interactionRadius"][0]), float(P["timestep"][0]), float(P["soundSpeed"][0])
+        # the reference steps with a FIXED dt (sph.cpp:60; its CFL rule is compiled out, sph.cpp:217-231): once |v|max passes
+        # 0.4 h / dt - c_s the integration is beyond its stability limit and the column eventually blows up
+        rec["vmax"] = vmax
+        rec["cfl_dt_limit"] = 0.4 * h / (cs + vmax)
+        rec["dt"] = dtp
+    except capi.NereusError:
+        pass
+    try:
         rec["mover_fraction_last_step"] = s.get_stat(capi.STAT_MOVERS) / n
         rec["hit_list_overflow_fraction"] = s.get_stat(capi.STAT_HIT_OVERFLOW) / n
         rec["neighbours_mean"] = s.get_stat(capi.STAT_HIT_MEAN)
@@ -256,7 +267,16 @@ def main():
             if lattice[0] % world:
                 raise SystemExit("--scaling strong needs the x extent of the lattice (%d) divisible by --gpus" % lattice[0])
             lattice = (lattice[0] // world,) + tuple(lattice[1:])
-        result = slab.bench_main(args, lattice, rank, world, local_rank)
+        # RCCL prints a version banner on STDOUT when its communicator comes up: keep fd 1 for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            result = slab.bench_main(args, lattice, rank, world, local_rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         result["scaling"] = args.scaling
         if rank == 0:
             print(json.dumps(result))
