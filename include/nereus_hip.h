@@ -81,6 +81,12 @@ enum {
                                            with the default reference-order IEEE arithmetic to ~1e-6 relative per step.  The
                                            reference itself is built with --use_fast_math (CMakeLists.txt:85).  Ignored (exact
                                            arithmetic) for fp64, Monaghan kernels, IISPH and NRS_FLAG_REFERENCE_ORDER. */
+    NRS_FLAG_IISPH_SELF_BY_SLOT = 1u << 6, /* IISPH: computePressure / computePressureForce exclude the particle ITSELF from their
+                                           neighbour sums.  The reference excludes the slot whose number equals the CUDA thread
+                                           id instead (sph_kernel_impl.cuh:1412,1568), which makes its result depend
+                                           on the ORDER of the input arrays: the same particles permuted differ by centimetres
+                                           after four steps.  Default off = the reference's behaviour; a
+                                           multi-GPU slab run can only be compared with a single-domain run with this flag on. */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };
@@ -245,7 +251,8 @@ int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches);
  * nrs_step then evaluates density on owned particles plus one cell beyond each cut and forces on owned particles
  * only.  Message buffer: nrs_slab_message_bytes(capacity, precision) bytes =
  *   [u32 nMigrants, u32 nHalo, u32 0, u32 0 | vec4 pos[capacity] | vec4 vel[capacity]].
- * Pass NULL for the neighbour that does not exist (ends of the chain).  SESPH only in this version. */
+ * Pass NULL for the neighbour that does not exist (ends of the chain).  IISPH contexts: halo_cells >= 8 and the step is driven
+ * through nrs_iisph_predict / _iterate / _finish (below). */
 int nrs_slab_configure(nrs_ctx *ctx, int32_t cell_lo, int32_t cell_hi, int32_t halo_cells);
 /* counts (optional) receives {stay, migrate-left, halo-left, migrate-right, halo-right, ghost}. */
 int nrs_slab_pack(nrs_ctx *ctx, void *send_left, void *send_right, uint64_t capacity, uint32_t counts[6]);
@@ -257,6 +264,22 @@ uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision);
  * of a count-balanced re-cut.  New cuts are applied by calling nrs_slab_configure again; particles that now belong
  * to a neighbour leave with the next nrs_slab_pack (a cut may therefore move by less than a slab width at a time). */
 int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts);
+
+/* IISPH step in three calls, for runs in which the solver loop's exit test needs a value the library cannot form alone — a slab
+ * run: pressureSolve (sph_cuda.cu:736-741) loops `while ((rho_avg - 1000) > 1 || l < 2)` with rho_avg the average predicted
+ * density over ALL particles, i.e. over all ranks.
+ *   nrs_iisph_predict   hash / sort / reorder + predictAdvection (density, displacement factors, advection factors)
+ *   nrs_iisph_iterate   ONE relaxed-Jacobi iteration; returns the sum of the corrected densities over the particles this rank
+ *                       owns and their number (all particles of a single-domain context): the caller adds these up over the
+ *                       ranks (one scalar all-reduce), forms rho_avg = (SReal)sum / count and decides
+ *   nrs_iisph_finish    pressure force + integration
+ * nrs_step on an IISPH context is the same three phases with the loop inside.  Slab runs (nrs_slab_configure on an IISPH context)
+ * need a halo of at least 2 * iterations + 4 cells — every iteration consumes two cells of halo validity, the predict stages three,
+ * the pressure force one — i.e. >= 8; nrs_iisph_iterate fails with NRS_E_STATE when the loop runs longer than the halo supports.
+ * The warm-start pressure of every particle travels in vel.w of the slab messages (iisph_integrate zeroes vel.w anyway). */
+int nrs_iisph_predict(nrs_ctx *ctx);
+int nrs_iisph_iterate(nrs_ctx *ctx, double *sum_density_corr, uint64_t *count);
+int nrs_iisph_finish(nrs_ctx *ctx);
 
 /* Coherent re-sort statistics since nrs_create: steps whose (hash, index) pairs were produced by sorting only the
  * particles that changed cell and merging them into the rest, and how many of those fell back to the full radix sort
@@ -281,6 +304,13 @@ int nrs_get_stat(nrs_ctx *ctx, int which, double *out);
  * SReal (precision 32/64), vbi: nb SReal, both HOST buffers; device < 0 = current device.  Uses the same hash / radix sort /
  * cell-range / 27-cell gather as the solver, on a private grid. */
 int nrs_boundary_volumes(int device, int precision, const void *bi4, uint64_t nb, double h, void *vbi);
+
+/* Test hook: the DEVICE smoothing kernels / vector helpers (common/kernels_impl.cuh:85-203, helper_math.h semantics) on n
+ * caller-supplied separations r3 (and second vectors s3, may be NULL), HOST buffers of 3n SReal; which = 0 Wdefault, 1
+ * Wdefault_grad, 2 Wpressure_grad, 3 Wviscosity_grad, 4 Wmonaghan, 5 Wmonaghan_grad, 8 dot, 9 length, 10 vec*float, 11 float*vec,
+ * 12 vec/float, 13 identity, 14 +, 15 - (the numbering of oracle/ref_kernels_driver.cpp; scalars land in out[3i]).  Lets the
+ * tests compare the product's arithmetic bit for bit with the reference's own header compiled unmodified. */
+int nrs_eval_smoothing(int precision, int which, uint64_t n, const void *r3, const void *s3, double h, double c0, double c1, void *out);
 
 /* maxDensity / maxVelocity (sph/sph.cuh, sph_cuda.cu:32-53): diagnostics over the sorted arrays. */
 int nrs_max_density(nrs_ctx *ctx, double *out);

@@ -21,6 +21,7 @@ FLAG_NO_FUSION = 4
 FLAG_NO_SHARED_LISTS = 8
 FLAG_FULL_SORT = 16
 FLAG_FAST_ARITH = 32
+FLAG_IISPH_SELF_BY_SLOT = 64
 E_NOTREADY = -6
 STAT_MOVERS, STAT_HIT_OVERFLOW, STAT_HIT_MEAN, STAT_HIT_MAX, STAT_UNSTAGED = 0, 1, 2, 3, 4
 
@@ -50,7 +51,7 @@ EXPORTS = [
     "nrs_last_iterations", "nrs_set_max_iterations", "nrs_set_profiling", "nrs_stage_ms", "nrs_max_density",
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
     "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats", "nrs_snapshot_begin", "nrs_snapshot_wait",
-    "nrs_get_stat", "nrs_boundary_volumes",
+    "nrs_get_stat", "nrs_boundary_volumes", "nrs_eval_smoothing", "nrs_iisph_predict", "nrs_iisph_iterate", "nrs_iisph_finish",
 ]
 
 
@@ -115,6 +116,10 @@ def load_library(path=None):
     lib.nrs_slab_histogram.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.nrs_resort_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.nrs_get_stat.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    lib.nrs_iisph_predict.argtypes = [vp]
+    lib.nrs_iisph_iterate.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    lib.nrs_iisph_finish.argtypes = [vp]
+    lib.nrs_eval_smoothing.argtypes = [i32, i32, u64, vp, vp, C.c_double, C.c_double, C.c_double, vp]
     lib.nrs_boundary_volumes.argtypes = [i32, i32, vp, u64, C.c_double, vp]
     lib.nrs_snapshot_begin.argtypes = [vp, i32]
     lib.nrs_snapshot_wait.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
@@ -133,6 +138,19 @@ def boundary_volumes(bi4, h, double=False, device=-1):
     bi4 = np.ascontiguousarray(bi4, dtype=real).reshape(-1, 4)
     out = np.empty(bi4.shape[0], dtype=real)
     rc = lib.nrs_boundary_volumes(int(device), 64 if double else 32, _ptr(bi4), bi4.shape[0], float(h), _ptr(out))
+    if rc != 0:
+        raise NereusError("libnereus_hip error %d: %s" % (rc, lib.nrs_last_error().decode()))
+    return out
+
+
+def eval_smoothing(which, r, s, h, c0, c1, double=False):
+    """device smoothing kernel / vector helper number `which` on separations r (n,3) [and s]; returns (n,3) (nrs_eval_smoothing)"""
+    lib = load_library()
+    real = np.float64 if double else np.float32
+    r = np.ascontiguousarray(r, dtype=real)
+    s = None if s is None else np.ascontiguousarray(s, dtype=real)
+    out = np.zeros_like(r)
+    rc = lib.nrs_eval_smoothing(64 if double else 32, int(which), r.shape[0], _ptr(r), _ptr(s), float(h), float(c0), float(c1), _ptr(out))
     if rc != 0:
         raise NereusError("libnereus_hip error %d: %s" % (rc, lib.nrs_last_error().decode()))
     return out
@@ -317,6 +335,18 @@ class Solver:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self.lib.nrs_resort_stats(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def iisph_predict(self):
+        self._chk(self.lib.nrs_iisph_predict(self.h))
+
+    def iisph_iterate(self):
+        """one solver iteration; returns (sum of corrected densities over the owned particles, their number)"""
+        sm, cnt = C.c_double(0), C.c_uint64(0)
+        self._chk(self.lib.nrs_iisph_iterate(self.h, C.byref(sm), C.byref(cnt)))
+        return sm.value, int(cnt.value)
+
+    def iisph_finish(self):
+        self._chk(self.lib.nrs_iisph_finish(self.h))
 
     def get_stat(self, which):
         v = C.c_double()

@@ -210,6 +210,21 @@ int nrs_resort_stats(nrs_ctx *ctx, uint64_t *steps, uint64_t *fallbacks)
     ctx->impl->resort_stats(steps, fallbacks);
     return NRS_OK;
 }
+int nrs_iisph_predict(nrs_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->iisph_phase(0, nullptr, nullptr);
+}
+int nrs_iisph_iterate(nrs_ctx *ctx, double *sum_density_corr, uint64_t *count)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->iisph_phase(1, sum_density_corr, count);
+}
+int nrs_iisph_finish(nrs_ctx *ctx)
+{
+    CTX_GUARD(ctx);
+    return ctx->impl->iisph_phase(2, nullptr, nullptr);
+}
 int nrs_get_stat(nrs_ctx *ctx, int which, double *out)
 {
     CTX_GUARD(ctx);

@@ -78,6 +78,7 @@ struct CtxBase {
     virtual int slab_histogram(int lo0, uint32_t nbins, uint32_t *out) = 0;
     virtual void resort_stats(uint64_t *steps, uint64_t *fallbacks) = 0;
     virtual int get_stat(int which, double *out) = 0;
+    virtual int iisph_phase(int phase, double *sum, uint64_t *count) = 0;
     virtual int set_profiling(uint32_t mask) = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;

@@ -322,7 +322,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(errWord.alloc(4));
         HIPCHK(hipMemsetAsync(errWord.p, 0, 4, stream));
         NRSCHK(redPartial.alloc(sizeof(double) * 1024));
-        NRSCHK(redOut.alloc(sizeof(double)));
+        NRSCHK(redOut.alloc(2 * sizeof(double)));
         // radix sort workspace for the largest problem
         size_t tmp = 0;
         rocprim::double_buffer<uint32_t> k(hashA.as<uint32_t>(), hashB.as<uint32_t>());
@@ -690,6 +690,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                                cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
                                wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>());
+        if (iisph() && (cfg.flags & NRS_FLAG_IISPH_SELF_BY_SLOT)) // Q5 off: the pressure kernels skip j == own slot
+            hipLaunchKernelGGL(k_identity, g, b, 0, stream, inv.as<uint32_t>(), N);
         NRSCHK(ev_end());
         return NRS_OK;
     }
@@ -892,15 +894,21 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
-    template <bool HAS_B> int iisph_tail(int stop)
+    // ---- IISPH step in three phases (the single-domain nrs_step runs them back to back; a slab run has the host decide after
+    //      every solver iteration, on the sum over ALL ranks: nrs_iisph_predict / _iterate / _finish) -----------------------------
+    uint32_t iisphIter = 0;  // solver iterations done in the current step
+    int iisphPhase = 0;      // 0 idle, 1 predicted (iterations may follow)
+    bool iisph_lists() const { return !refOrder() && hitBuf.p != nullptr && KSET == KS_MULLER; }
+
+    // predictAdvection (sph_cuda.cu:513-697)
+    template <bool HAS_B> int iisph_predict(int stop)
     {
         const uint32_t N = (uint32_t)n;
         const dim3 g(nblocks(N)), b(BLOCK);
         const GridView<R> G = grid_view();
         IisphArrays<R> I = iisph_view();
-        // predictAdvection (sph_cuda.cu:513-697)
         // one neighbourhood scan per step: its hit lists drive the rest of the chain (nrs_kernels_iisph.h)
-        const bool lists = !refOrder() && hitBuf.p != nullptr && KSET == KS_MULLER;
+        const bool lists = iisph_lists();
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
         if (lists) launch_density_wide<R, KSET, HAS_B>(stream, P, G, hb, posB.as<T4>(), dens.as<R>(), N);
@@ -924,7 +932,73 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             hipLaunchKernelGGL((k_advection_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
                                dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());
-        if (stop == NRS_STAGE_I_ADVECTION) return NRS_OK;
+        iisphIter = 0;
+        return NRS_OK;
+    }
+    // one relaxed-Jacobi iteration of pressureSolve (sph_cuda.cu:736-823): sum d_ij p_j, pressure update (double-buffered P_l)
+    template <bool HAS_B> int iisph_iteration()
+    {
+        const uint32_t N = (uint32_t)n;
+        const dim3 g(nblocks(N)), b(BLOCK);
+        const GridView<R> G = grid_view();
+        IisphArrays<R> I = iisph_view();
+        const bool lists = iisph_lists();
+        const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
+        if (lists) hipLaunchKernelGGL((k_sumdij_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), N);
+        else hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
+        if (lists)
+            hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        else
+            hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
+                               presB.as<R>(), N);
+        std::swap(P_l.p, P_l2.p);
+        ++iisphIter;
+        return NRS_OK;
+    }
+    // computePressureForce + iisph_integrate (sph_cuda.cu:827-867)
+    template <bool HAS_B> int iisph_finish(int stop)
+    {
+        const uint32_t N = (uint32_t)n;
+        const dim3 g(nblocks(N)), b(BLOCK);
+        const GridView<R> G = grid_view();
+        IisphArrays<R> I = iisph_view();
+        const bool lists = iisph_lists();
+        const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
+        NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
+        if (lists)
+            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        else
+            hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        NRSCHK(ev_end());
+        if (stop == NRS_STAGE_I_PFORCE) return NRS_OK;
+        NRSCHK(ev_begin(NRS_STAGE_I_INTEGRATE));
+        // a full step on the production kernels also leaves the next step's sort keys (and the split of the coherent
+        // re-sort), as the fused SESPH force kernel does — not in slab runs, whose arrays are re-partitioned first
+        const bool keys = !refOrder() && stop == 0 && !(cfg.flags & NRS_FLAG_NO_FUSION) && !slabOn;
+        const bool resort = keys && rsMovers.p && (uint64_t)N >= RESORT_MIN_PARTICLES;
+        uint32_t *nh = nullptr, *ni = nullptr;
+        if (keys) {
+            nh = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
+            ni = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+        }
+        if (resort) NRSCHK(clean_tile_counts());
+        hipLaunchKernelGGL((k_iisph_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), velAdv.as<T4>(), forcesP.as<T4>(), N,
+                           nh, ni, resort ? (const uint32_t *)hashCur : (const uint32_t *)nullptr,
+                           resort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr, slabOn ? 1 : 0);
+        NRSCHK(ev_end());
+        if (keys) {
+            hashNext = nh; indexNext = ni;
+            hashReady = true;
+            if (resort) NRSCHK(queue_resort_split(N));
+        }
+        return NRS_OK;
+    }
+
+    template <bool HAS_B> int iisph_tail(int stop)
+    {
+        const uint32_t N = (uint32_t)n;
+        NRSCHK(iisph_predict<HAS_B>(stop));
+        if (stop && stop <= NRS_STAGE_I_ADVECTION) return NRS_OK;
         // pressureSolve (sph_cuda.cu:702-899): while ((rho_avg - 1000) > 1 || l < 2)
         NRSCHK(ev_begin(NRS_STAGE_I_SOLVE));
         uint32_t l = 0;
@@ -932,15 +1006,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const R rd = 1000.f;
         const R max_rho_err = 1.f;
         while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
-            if (lists) hipLaunchKernelGGL((k_sumdij_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), N);
-            else hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
-            if (lists)
-                hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
-            else
-                hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
-                                   presB.as<R>(), N);
-            std::swap(I.P_l, I.P_l_next);
-            std::swap(P_l.p, P_l2.p);
+            NRSCHK(iisph_iteration<HAS_B>());
             l++;
             if (maxIters && l >= maxIters) break;
             // the loop condition reads rho_avg only once l >= 2 (sph_cuda.cu:736: `|| l < 2`): the average of the first
@@ -955,40 +1021,60 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         lastIters = l;
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_SOLVE) return NRS_OK;
-        NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
-        if (lists)
-            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
-        else
-            hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
-        NRSCHK(ev_end());
-        if (stop == NRS_STAGE_I_PFORCE) return NRS_OK;
-        NRSCHK(ev_begin(NRS_STAGE_I_INTEGRATE));
-        // a full step on the production kernels also leaves the next step's sort keys (and the split of the coherent
-        // re-sort), as the fused SESPH force kernel does
-        const bool keys = !refOrder() && stop == 0 && !(cfg.flags & NRS_FLAG_NO_FUSION);
-        const bool resort = keys && rsMovers.p && (uint64_t)N >= RESORT_MIN_PARTICLES;
-        uint32_t *nh = nullptr, *ni = nullptr;
-        if (keys) {
-            nh = (hashCur == hashA.as<uint32_t>()) ? hashB.as<uint32_t>() : hashA.as<uint32_t>();
-            ni = (indexCur == indexA.as<uint32_t>()) ? indexB.as<uint32_t>() : indexA.as<uint32_t>();
+        return iisph_finish<HAS_B>(stop);
+    }
+
+    // ---- host-driven IISPH step (multi-GPU: the loop exit needs the average over ALL ranks) ---------------------------------
+    int iisph_phase(int phase, double *sum, uint64_t *count) override
+    {
+        if (!iisph()) return fail(NRS_E_STATE, "not an IISPH context");
+        NRSCHK(validate("nrs_iisph_*"));
+        if (phase == 0) { // predict
+            if (midStep || iisphPhase) return fail(NRS_E_STATE, "a step is already in progress");
+            if (n == 0) return NRS_OK;
+            fusedThisStep = false; splitClearedCells = false;
+            NRSCHK(stage_prefix(0));
+            if (nb) NRSCHK(iisph_predict<true>(0)); else NRSCHK(iisph_predict<false>(0));
+            iisphPhase = 1;
+            return NRS_OK;
         }
-        if (resort) NRSCHK(clean_tile_counts());
-        hipLaunchKernelGGL((k_iisph_integrate<R>), g, b, 0, stream, P, posB.as<T4>(), velB.as<T4>(), velAdv.as<T4>(), forcesP.as<T4>(), N,
-                           nh, ni, resort ? (const uint32_t *)hashCur : (const uint32_t *)nullptr,
-                           resort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr);
-        NRSCHK(ev_end());
-        if (keys) {
-            hashNext = nh; indexNext = ni;
-            hashReady = true;
-            if (resort) NRSCHK(queue_resort_split(N));
+        if (!iisphPhase) return fail(NRS_E_STATE, "nrs_iisph_predict first");
+        if (phase == 1) { // one iteration + the density-error sum over the particles this rank owns
+            if (slabOn && (int)iisphIter >= slabMaxIters())
+                return fail(NRS_E_STATE, "IISPH slab run: more solver iterations than the halo width supports (halo >= 2 * iterations + 4 cells)");
+            if (nb) NRSCHK(iisph_iteration<true>()); else NRSCHK(iisph_iteration<false>());
+            const uint32_t N = (uint32_t)n, nbk = std::min<uint32_t>(1024u, nblocks(N));
+            unsigned long long *cnt = (unsigned long long *)((char *)redOut.p); // redOut: [double sum][u64 count]
+            HIPCHK(hipMemsetAsync(redOut.p, 0, 16, stream));
+            hipLaunchKernelGGL((k_sum_partial<R>), dim3(nbk), dim3(BLOCK), 0, stream, densCorr.as<R>(), redPartial.as<double>(), N,
+                               slabOn ? posB.as<T4>() : (const T4 *)nullptr, cnt + 1);
+            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(BLOCK), 0, stream, redPartial.as<double>(), redOut.as<double>(), nbk);
+            double h[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h, redOut.p, 16, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            unsigned long long c;
+            std::memcpy(&c, &h[1], 8);
+            if (sum) *sum = h[0];
+            if (count) *count = slabOn ? (uint64_t)c : (uint64_t)N;
+            lastIters = iisphIter;
+            return NRS_OK;
         }
+        // finish
+        if (iisphIter == 0) return fail(NRS_E_STATE, "nrs_iisph_iterate at least once before nrs_iisph_finish");
+        if (nb) NRSCHK(iisph_finish<true>(0)); else NRSCHK(iisph_finish<false>(0));
+        HIPCHK(hipGetLastError());
+        NRSCHK(end_of_step());
+        iisphPhase = 0;
         return NRS_OK;
     }
+    int slabMaxIters() const { return (slab.halo - 4) / 2; }
 
     // ---- slab decomposition (nrs_kernels_slab.h) -------------------------------------------------------
     int slab_configure(int lo, int hi, int halo) override
     {
-        if (iisph()) return fail(NRS_E_STATE, "slab decomposition is implemented for the SESPH solver only");
+        // IISPH: every solver iteration consumes two cells of halo validity, the predict stages three and the pressure force one
+        // (DESIGN.md §5): 2 iterations — the reference's minimum — need 8 cells
+        if (iisph() && halo < 8) return fail(NRS_E_INVALID, "IISPH slabs need a halo of at least 8 cells (2 * iterations + 4)");
         if (halo < 2) return fail(NRS_E_INVALID, "halo must be >= 2 cells (one cell for the density of the ring + one)");
         if ((long long)hi - lo < 2ll * halo) return fail(NRS_E_INVALID, "slab narrower than two halos");
         if (classifiedValid && (slab.lo != lo || slab.hi != hi || slab.halo != halo)) {
@@ -1058,6 +1144,9 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
         if (mcap == 0 || mcap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
         NRSCHK(compact_holes()); // (a pack right after a pack/unpack without a step in between)
+        if (iisphPhase) return fail(NRS_E_STATE, "a host-driven IISPH step is in progress");
+        if (iisph() && n) // the warm-start pressure travels in vel.w (k_pressure_to_velw)
+            hipLaunchKernelGGL((k_pressure_to_velw<R>), dim3(nblocks(n)), dim3(BLOCK), 0, stream, velA.as<T4>(), presA.as<R>(), (uint32_t)n);
         const uint32_t N = (uint32_t)n;
         const uint32_t nbk = std::max<uint32_t>(1u, (N + SLAB_TILE - 1) / SLAB_TILE);
         NRSCHK(slabCounts.alloc((size_t)ST_TOTALS * ((cap_blocks() > nbk) ? cap_blocks() : nbk) * 4));
@@ -1239,6 +1328,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         HIPCHK(hipGetLastError());
         nOwned = n + hL[0] + hR[0];
         n = total;
+        if (iisph() && n)
+            hipLaunchKernelGGL((k_velw_to_pressure<R>), dim3(nblocks(n)), dim3(BLOCK), 0, stream, velA.as<T4>(), presA.as<R>(), (uint32_t)n);
         // pack + unpack have written the radix keys/values of every local particle
         hashNext = packKeys; indexNext = packVals;
         hashReady = packedHashValid;
@@ -1303,8 +1394,27 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         *out = which == NRS_STAT_HIT_OVERFLOW ? (double)h[0] : (which == NRS_STAT_HIT_MEAN ? (double)h[1] / (double)N : (which == NRS_STAT_HIT_MAX ? (double)h[2] : (double)h[3]));
         return NRS_OK;
     }
+    // bookkeeping at the end of a completed step (cell-table undo, buffer swaps)
+    int end_of_step()
+    {
+        if ((uint64_t)P.numCells > 8ull * n) { // big, mostly empty table: undo only the touched cells
+            if (!splitClearedCells)
+                hipLaunchKernelGGL(k_clear_cells, dim3(nblocks(n)), dim3(BLOCK), 0, stream, hashCur, cellStart.as<uint32_t>(), (uint32_t)n);
+            cellsClean = true;
+        }
+        // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
+        ++stepsDone;
+        slotOrderValid = fusedThisStep; // A holds the new state in the slot order of hashCur
+        if (!fusedThisStep) { // the fused kernel already wrote the new state into A
+            std::swap(posA.p, posB.p);
+            std::swap(velA.p, velB.p);
+        }
+        if (iisph()) std::swap(presA.p, presB.p);
+        return NRS_OK;
+    }
     int step(int nsteps, int stop) override
     {
+        if (iisphPhase) return fail(NRS_E_STATE, "a host-driven IISPH step is in progress (nrs_iisph_finish first)");
         NRSCHK(validate("nrs_step"));
         if (midStep) return fail(NRS_E_STATE, "state is mid-update after nrs_step_partial; upload particles first");
         if (n == 0) return NRS_OK;
@@ -1317,19 +1427,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             else { if (nb) NRSCHK(sesph_tail<true>(stop)); else NRSCHK(sesph_tail<false>(stop)); }
             HIPCHK(hipGetLastError());
             if (stop) { midStep = true; break; }
-            if ((uint64_t)P.numCells > 8ull * n) { // big, mostly empty table: undo only the touched cells
-                if (!splitClearedCells)
-                    hipLaunchKernelGGL(k_clear_cells, dim3(nblocks(n)), dim3(BLOCK), 0, stream, hashCur, cellStart.as<uint32_t>(), (uint32_t)n);
-                cellsClean = true;
-            }
-            // the integrated sorted arrays become the next step's input (replaces D2H + H2D)
-            ++stepsDone;
-            slotOrderValid = fusedThisStep; // A holds the new state in the slot order of hashCur
-            if (!fusedThisStep) { // the fused kernel already wrote the new state into A
-                std::swap(posA.p, posB.p);
-                std::swap(velA.p, velB.p);
-            }
-            if (iisph()) std::swap(presA.p, presB.p);
+            NRSCHK(end_of_step());
         }
         HIPCHK(hipGetLastError());
         if (evUsed > 8192) NRSCHK(ev_collect()); // bound the pool of pending event pairs

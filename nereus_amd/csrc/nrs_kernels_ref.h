@@ -349,6 +349,22 @@ __global__ __launch_bounds__(BLOCK) void k_forces_ref(Params<R> P, GridView<R> G
     forces[i] = mk4<R>(f, (R)0);
 }
 
+// IISPH slab runs: the warm-start pressure of a particle (p0 = 0.5 p of the last step, sph_kernel_impl.cuh:1187) has to travel
+// with it through the partition and the messages.  vel.w is free for that — iisph_integrate zeroes it every step
+// (sph_kernel_impl.cuh:1654) — so the pressure rides there from nrs_slab_pack to nrs_slab_unpack.
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_pressure_to_velw(typename Vec4T<R>::type *__restrict__ vel, const R *__restrict__ pres, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) vel[i].w = pres[i];
+}
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_velw_to_pressure(typename Vec4T<R>::type *__restrict__ vel, R *__restrict__ pres, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) { pres[i] = vel[i].w; vel[i].w = (R)0; }
+}
+
 // ---- integrate_functor (sph_kernel_impl.cuh:71-100): symplectic Euler, w components kept --------------
 template <typename R>
 __global__ __launch_bounds__(BLOCK) void k_integrate(Params<R> P, typename Vec4T<R>::type *__restrict__ pos,
@@ -586,6 +602,13 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_ref(Params<R> P, GridView<R> G
     I.sumDij[i] = mk4<R>(dijpj, (R)0.0);
 }
 
+// NRS_FLAG_IISPH_SELF_BY_SLOT: inv[slot] = slot, so that the two kernels below skip the particle itself (SURVEY Q5 off)
+static __global__ __launch_bounds__(BLOCK) void k_identity(uint32_t *__restrict__ a, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
 // computePressure (sph_kernel_impl.cuh:1330-1492): relaxed Jacobi, omega = 0.5.
 // Q5: the fluid loop skips j == inv[i] (the reference thread id), not j == i.
 // Q6: the boundary loop runs j from the FLUID cell start to the boundary cell end.
@@ -719,7 +742,7 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename
                                                            const typename Vec4T<R>::type *__restrict__ forcesP,
                                                            uint32_t n, uint32_t *__restrict__ nextHash,
                                                            uint32_t *__restrict__ nextIndex, const uint32_t *__restrict__ prevHash,
-                                                           uint32_t *__restrict__ tileMovers)
+                                                           uint32_t *__restrict__ tileMovers, int keepHaloMark)
 {
     // nextHash/nextIndex (both or neither): also emit the next step's sort keys (calcHashD of the new position);
     // prevHash/tileMovers (both or neither): count the slots whose key changes, for the coherent re-sort
@@ -731,7 +754,10 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename
     const V3<R> fpres1 = xyz<R>(forcesP[i]);
     const V3<R> newVel = velAdv1 + (dt * fpres1 / pm);
     const V3<R> newPos = pos1 + (dt * newVel);
-    pos[i] = mk4<R>(newPos, (R)1.0);
+    // the reference sets w = 1 / 0 here (sph_kernel_impl.cuh:1653-1654); slab runs keep the w = 2 that marks a halo copy (not a
+    // particle of this rank: it is dropped by the next partition)
+    const R w0 = pos[i].w;
+    pos[i] = mk4<R>(newPos, (keepHaloMark && w0 == (R)2.0) ? (R)2.0 : (R)1.0);
     vel[i] = mk4<R>(newVel, (R)0.0);
     if (nextHash) {
         const I3 g = calcGridPos<R>(P, newPos);
@@ -744,11 +770,23 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_integrate(Params<R> P, typename
 
 // deterministic two-pass sum of an SReal array in double (replaces thrust::reduce, sph_cuda.cu:816-819)
 template <typename R>
-__global__ __launch_bounds__(BLOCK) void k_sum_partial(const R *__restrict__ a, double *__restrict__ partial, uint32_t n)
+__global__ __launch_bounds__(BLOCK) void k_sum_partial(const R *__restrict__ a, double *__restrict__ partial, uint32_t n,
+                                                       const typename Vec4T<R>::type *__restrict__ ownedPos = nullptr,
+                                                       unsigned long long *__restrict__ ownedCount = nullptr)
 {
+    // ownedPos (slab runs): only the slots that hold a particle of this rank (pos.w == 1) count; their number goes to ownedCount
     __shared__ double sm[BLOCK / 64];
     double acc = 0.0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) acc += (double)a[i];
+    unsigned long long cnt = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        if (ownedPos && !(ownedPos[i].w == (R)1.0)) continue;
+        acc += (double)a[i];
+        ++cnt;
+    }
+    if (ownedCount) {
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(ownedCount, cnt);
+    }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();

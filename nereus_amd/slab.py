@@ -24,6 +24,7 @@ from . import scene
 from .params import default_params, update_grid
 
 HALO_CELLS = 2
+IISPH_HALO_CELLS = 8   # 2 * solver iterations + 4 (include/nereus_hip.h, nrs_iisph_*): the reference's minimum of 2 iterations
 NO_CUT_LO = -(1 << 29)
 NO_CUT_HI = (1 << 29)
 
@@ -80,7 +81,7 @@ def new_cuts(hist, old, halo, move_budget):
 class HipSlabEngine:
     """Product engine: particles live in an nrs_ctx on this rank's GPU; buffers are torch CUDA tensors."""
 
-    def __init__(self, params, capacity, msg_capacity, cell_lo, cell_hi, device_index, halo=HALO_CELLS):
+    def __init__(self, params, capacity, msg_capacity, cell_lo, cell_hi, device_index, halo=HALO_CELLS, iisph=False, flags=0):
         import torch
 
         from . import capi
@@ -93,7 +94,9 @@ class HipSlabEngine:
         # nothing against the solver's (the receive could still be in flight when nrs_slab_unpack reads the headers).
         self.stream = torch.cuda.Stream(device=self.device)
         assert self.stream.cuda_stream != 0
-        self.solver = capi.Solver(params, capacity, solver=capi.SESPH, device=device_index, stream=self.stream.cuda_stream)
+        self.iisph = bool(iisph)
+        self.solver = capi.Solver(params, capacity, solver=capi.IISPH if iisph else capi.SESPH, device=device_index,
+                                  stream=self.stream.cuda_stream, flags=flags)
         self.cell_lo, self.cell_hi, self.halo = cell_lo, cell_hi, halo
         self.msg_bytes = self.solver.message_bytes(self.msg_capacity)
         self._configured = False
@@ -101,8 +104,8 @@ class HipSlabEngine:
     def make_buffer(self):
         return self.torch.zeros(self.msg_bytes, dtype=self.torch.uint8, device=self.device)
 
-    def load(self, pos, vel, bi, vbi):
-        self.solver.set_particles(pos, vel)
+    def load(self, pos, vel, bi, vbi, pres=None):
+        self.solver.set_particles(pos, vel, pres)
         self.solver.set_boundaries(bi, vbi, update_grid=False)
         self.solver.slab_configure(self.cell_lo, self.cell_hi, self.halo)
         self._configured = True
@@ -117,6 +120,16 @@ class HipSlabEngine:
 
     def step(self, k=1):
         self.solver.step(k)
+
+    # IISPH: the solver loop is driven by SlabDriver.step (its exit test needs the average over all ranks)
+    def iisph_predict(self):
+        self.solver.iisph_predict()
+
+    def iisph_iterate(self):
+        return self.solver.iisph_iterate()
+
+    def iisph_finish(self):
+        self.solver.iisph_finish()
 
     def histogram(self, first_cell, ncells):
         """owned particles per global cell-x column (numpy int64)"""
@@ -203,7 +216,32 @@ class SlabDriver:
     def step(self, k=1):
         for _ in range(k):
             self.exchange()
-            self.engine.step(1)
+            if getattr(self.engine, "iisph", False):
+                self.iisph_step()
+            else:
+                self.engine.step(1)
+
+    def iisph_step(self):
+        """IISPH::update() over the slabs: pressureSolve's loop `while ((rho_avg - 1000) > 1 || l < 2)` (sph_cuda.cu:736-741)
+        with rho_avg formed from the sums of ALL ranks — one two-scalar all-reduce per iteration, the reference's
+        thrust::reduce + host round trip (sph_cuda.cu:816-819) made global.  Returns the iteration count."""
+        torch, dist, eng = self.torch, self.dist, self.engine
+        real = np.float32 if not getattr(eng, "double", False) else np.float64
+        eng.iisph_predict()
+        it, rho_avg = 0, real(0)
+        while (float(rho_avg) - 1000.0) > 1.0 or it < 2:
+            s, c = eng.iisph_iterate()
+            t = torch.tensor([s, float(c)], dtype=torch.float64)
+            dev = getattr(eng, "device", None) if dist.get_backend(self.group) == "nccl" else None
+            if dev is not None:
+                t = t.to(dev)
+            dist.all_reduce(t, group=self.group)
+            tot, cnt = (float(v) for v in t.cpu())
+            rho_avg = real(real(tot) / real(cnt))   # `rho_avg = (SReal)acc; rho_avg /= N` (sph_cuda.cu:818-819)
+            it += 1
+        eng.iisph_finish()
+        self.last_iterations = it
+        return it
 
     def rebalance(self, grid_x, move_budget):
         """Count-balanced re-cut (a dam-break starts with all fluid in one third of the tank and then

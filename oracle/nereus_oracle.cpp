@@ -219,6 +219,8 @@ struct Sim {
     SphSimParams P;
     SUint N = 0, Nb = 0;
     int jacobi = 1;          /* Q7: 1 = double-buffered P_l (our defined semantics), 0 = in place */
+    int selfBySlot = 0;      /* Q5 off: exclude the particle itself (j == own slot) instead of the thread id; the result then no
+                                longer depends on the ORDER of the input arrays (used to compare slab runs with single-domain ones) */
     int threads = 1;
     SUint lastIters = 0;
     /* host */
@@ -802,7 +804,7 @@ static void k_pressure(Sim &S, const Grid &G)
                     if (s != EMPTY) {
                         const SUint e = G.cellEnd[h];
                         for (SUint j = s; j < e; ++j) {
-                            if (j == t) continue; /* Q5 */
+                            if (j == (S.selfBySlot ? slot : t)) continue; /* Q5 */
                             const SVec3 d = pos1 - mk3(S.sPos[j]);
                             const SReal p_lj = Pold[j];
                             SVec3 grad = W_GRAD(d, ir, kpg);
@@ -866,7 +868,7 @@ static void k_pressureForce(Sim &S, const Grid &G)
                     if (s != EMPTY) {
                         const SUint e = G.cellEnd[h];
                         for (SUint j = s; j < e; ++j) {
-                            if (j == t) continue; /* Q5 */
+                            if (j == (S.selfBySlot ? slot : t)) continue; /* Q5 */
                             const SVec3 d = pos1 - mk3(S.sPos[j]);
                             const SReal pj = S.sPres[j];
                             const SReal densj = S.sDens[j];
@@ -974,7 +976,9 @@ static void iisphStep(Sim &S, int stop, int maxIters)
     SReal rho_avg = 0.f;
     const SReal rd = 1000.f;
     const SReal max_rho_err = 1.f;
-    while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
+    /* maxIters < 0 (slab checker engine, tests/slab_check_engine.py): exactly -maxIters iterations, whatever the LOCAL average
+     * says — in a slab run the exit test uses the average over all ranks */
+    while (maxIters < 0 ? (int)l < -maxIters : (((rho_avg - rd) > max_rho_err) || (l < 2))) {
         k_sumDijPj(S, G);
         k_pressure(S, G);
         /* thrust::reduce order is unspecified; both this oracle and the HIP path accumulate in double */
@@ -1168,6 +1172,7 @@ void orc_set_mode(void *h, int jacobi, int threads)
     S->jacobi = jacobi;
     S->threads = threads < 1 ? 1 : threads;
 }
+void orc_set_self_by_slot(void *h, int on) { ((Sim *)h)->selfBySlot = on; }
 void orc_set_particles(void *h, const SReal *pos4, const SReal *vel4, const SReal *pres, SUint n)
 {
     Sim *S = (Sim *)h;

@@ -9,7 +9,8 @@
  * function.  No builtin shim, no stand-in header, no copy of reference source: this file only CALLS them.
  * The recipe is oracle/Makefile target `ref`; outputs go to oracle/_ref/ (git-ignored, not gpurun-ignored).
  *
- * What it pins: SURVEY §8 rows a9 (smoothing kernels, common/kernels_impl.cuh:85-247) and a13 (float-scalar
+ * What it pins: SURVEY §8 rows a1 (the SphSimParams layout of common/sph_kernel.cuh:13-59, ref_params_layout), a9 (smoothing
+ * kernels, common/kernels_impl.cuh:85-247) and a13 (float-scalar
  * vector semantics, common/cuda_helpers/helper_math.h:817-829,1000-1008,1251-1301) — as the HOST compiler
  * resolves them (e.g. `pow(SReal,int)` at kernels_impl.cuh:95 is the double pow under g++).  Nothing else:
  * sph_kernel_impl.cuh needs nvcc builtins (threadIdx, __syncthreads, __umul24, <<<>>>) and is not built.
@@ -22,10 +23,30 @@
 #error "pass -DREF_KERNELS_IMPL='\"/root/reference/common/kernels_impl.cuh\"' (see oracle/Makefile)"
 #endif
 #include REF_KERNELS_IMPL
+#ifdef REF_SPH_KERNEL
+#include <cstddef>
+#include REF_SPH_KERNEL /* common/sph_kernel.cuh: the SphSimParams POD, also by path and unmodified */
+#endif
 
 extern "C" {
 
 int ref_sizeof_real(void) { return (int)sizeof(SReal); }
+
+#ifdef REF_SPH_KERNEL
+/* sizeof(SphSimParams) followed by the offset of every field, in declaration order (26 values) */
+int ref_params_layout(unsigned *out)
+{
+    unsigned k = 0;
+    out[k++] = (unsigned)sizeof(SphSimParams);
+#define OFF(f) out[k++] = (unsigned)offsetof(SphSimParams, f)
+    OFF(gridSize); OFF(numCells); OFF(worldOrigin); OFF(cellSize); OFF(numBodies); OFF(maxParticlesPerCell);
+    OFF(gasStiffness); OFF(viscosity); OFF(surfaceTension); OFF(restDensity); OFF(particleMass); OFF(interactionRadius);
+    OFF(timestep); OFF(particleRadius); OFF(gravity); OFF(soundSpeed); OFF(beta); OFF(kpoly); OFF(kpoly_grad); OFF(kpress_grad);
+    OFF(kvisc_grad); OFF(kvisc_denum); OFF(ksurf1); OFF(ksurf2); OFF(bpol);
+#undef OFF
+    return (int)k;
+}
+#endif
 
 /* which: 0 Wdefault(r,h,c0)  1 Wdefault_grad(r,h,c0)  2 Wpressure_grad(r,h,c0)  3 Wviscosity_grad(r,h,c0,c1)
  *        4 Wmonaghan(r,h)    5 Wmonaghan_grad(r,h)    6 Cakinci(r,h,c0,c1)      7 Aboundary(r,h,c0)

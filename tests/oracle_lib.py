@@ -45,6 +45,7 @@ def _load(double, kernel_set):
     lib.orc_set_params.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_get_params.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.orc_set_self_by_slot.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
     lib.orc_set_boundaries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
     lib.orc_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -72,7 +73,7 @@ def _ptr(a):
 class Oracle:
     """One simulated solver (mirrors the nrs_ctx API of the HIP library so tests read symmetrically)."""
 
-    def __init__(self, params=None, double=False, kernel_set=1, solver=SESPH, threads=1, jacobi=True):
+    def __init__(self, params=None, double=False, kernel_set=1, solver=SESPH, threads=1, jacobi=True, self_by_slot=False):
         self.double, self.kernel_set, self.solver = bool(double), int(kernel_set), solver
         self.real = np.float64 if double else np.float32
         self.lib = _load(double, kernel_set)
@@ -81,6 +82,8 @@ class Oracle:
         self._p = np.array(params, dtype=params_dtype(double)).reshape(1).copy()
         self.h = self.lib.orc_create(_ptr(self._p))
         self.lib.orc_set_mode(self.h, int(jacobi), int(threads))
+        if self_by_slot:  # SURVEY Q5 switched off: order-independent IISPH (see nereus_oracle.cpp, Sim::selfBySlot)
+            self.lib.orc_set_self_by_slot(self.h, 1)
 
     def __del__(self):
         try:

@@ -4,11 +4,16 @@ import numpy as np
 import torch
 
 from nereus_amd.slab import HALO_CELLS, cell_of
-from tests.oracle_lib import SESPH, Oracle
+from tests.oracle_lib import IISPH, SESPH, STOP_I_SOLVE, Oracle
 
 
 class OracleSlabEngine:
-    def __init__(self, params, msg_capacity, cell_lo, cell_hi, halo=HALO_CELLS):
+    def __init__(self, params, msg_capacity, cell_lo, cell_hi, halo=HALO_CELLS, iisph=False, self_by_slot=False):
+        self.iisph = bool(iisph)
+        self.self_by_slot = bool(self_by_slot)   # NRS_FLAG_IISPH_SELF_BY_SLOT
+        self.pres = np.zeros(0, np.float32)
+        self._pre = None
+        self._it = 0
         self.p = params.copy()
         self.cap = int(msg_capacity)
         self.lo, self.hi, self.halo = cell_lo, cell_hi, halo
@@ -22,8 +27,9 @@ class OracleSlabEngine:
     def make_buffer(self):
         return torch.zeros(self.msg_bytes, dtype=torch.uint8)
 
-    def load(self, pos, vel, bi, vbi):
+    def load(self, pos, vel, bi, vbi, pres=None):
         self.pos, self.vel, self.bi, self.vbi = pos.copy(), vel.copy(), bi, vbi
+        self.pres = np.zeros(len(pos), np.float32) if pres is None else np.asarray(pres, np.float32).copy()
         self._n_owned = len(pos)
 
     def _views(self, buf):
@@ -35,6 +41,9 @@ class OracleSlabEngine:
 
     def pack(self, send_left, send_right):
         ox, cs = float(self.p["worldOrigin"][0][0]), float(self.p["cellSize"][0][0])
+        if self.iisph:  # the warm-start pressure travels in vel.w, as in the library (k_pressure_to_velw)
+            self.vel = self.vel.copy()
+            self.vel[:, 3] = self.pres
         live = self.pos[:, 3] == 1.0
         pos, vel = self.pos[live], self.vel[live]
         cx = cell_of(pos[:, 0], ox, cs)
@@ -76,6 +85,9 @@ class OracleSlabEngine:
         self._n_owned = len(owned_p)
         self.pos = np.concatenate([owned_p, self._ghost[0]] + hal_p)
         self.vel = np.concatenate([owned_v, self._ghost[1]] + hal_v)
+        if self.iisph:
+            self.pres = self.vel[:, 3].copy()
+            self.vel[:, 3] = 0.0
 
     def step(self, k=1):
         o = Oracle(self.p, solver=SESPH)
@@ -84,6 +96,34 @@ class OracleSlabEngine:
             o.set_boundaries(self.bi, self.vbi, update_grid=False)
             o.step(1)
             self.pos, self.vel = o.get("pos"), o.get("vel")
+
+    # ---- IISPH in phases (same interface as HipSlabEngine): the oracle has no resumable solver loop, so every call re-runs the
+    #      step from the saved pre-state with a FORCED iteration count (max_iters < 0) — quadratic in the iteration count, fine
+    #      for test scenes
+    def _oracle(self, iters, stop):
+        o = Oracle(self.p, solver=IISPH, self_by_slot=self.self_by_slot)
+        pos, vel, pres = self._pre
+        o.set_particles(pos, vel, pres)
+        o.set_boundaries(self.bi, self.vbi, update_grid=False)
+        o.step(1, stop=stop, max_iters=-iters)
+        return o
+
+    def iisph_predict(self):
+        self._pre = (self.pos.copy(), self.vel.copy(), self.pres.copy())
+        self._it = 0
+
+    def iisph_iterate(self):
+        self._it += 1
+        o = self._oracle(self._it, STOP_I_SOLVE)
+        own = o.get("sortedPos")[:, 3] == 1.0
+        return float(o.get("densCorr").astype(np.float64)[own].sum()), int(own.sum())
+
+    def iisph_finish(self):
+        own = self._oracle(self._it, STOP_I_SOLVE).get("sortedPos")[:, 3] == 1.0   # halo marks, in the output (sorted) order
+        o = self._oracle(self._it, 0)
+        self.pos, self.vel, self.pres = o.get("pos").copy(), o.get("vel").copy(), o.get("pressure").copy()
+        self.pos[~own, 3] = 2.0   # iisph_integrate sets w = 1 everywhere; a slab run keeps the halo mark (k_iisph_integrate)
+        self._pre = None
 
     def histogram(self, first_cell, ncells):
         ox, cs = float(self.p["worldOrigin"][0][0]), float(self.p["cellSize"][0][0])

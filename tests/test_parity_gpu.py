@@ -444,6 +444,40 @@ def test_iisph_list_kernels_equal_reference_order_bitwise(hip_lib):
             np.testing.assert_array_equal(a, b, err_msg=nm)
 
 
+def test_iisph_self_by_slot_flag(hip_lib):
+    """NRS_FLAG_IISPH_SELF_BY_SLOT (SURVEY Q5 off): against the oracle in the same mode, both kernel paths; and the point of the
+    flag — the result no longer depends on the order of the input arrays (with the default flags it does, by centimetres)."""
+    from scipy.spatial import cKDTree
+
+    p, pos, vel = compressed_block()
+    vel = vel.copy()
+    vel[:, 0] = np.where(np.arange(len(pos)) % 2 == 0, 1.0, -1.0).astype(np.float32)   # movers, so that Q5 bites
+    perm = np.random.default_rng(3).permutation(len(pos))
+    o = Oracle(p, solver=IISPH, self_by_slot=True)
+    o.set_particles(pos, vel); o.set_boundaries(None, None)
+    o.step(4)
+    spread = {}
+    for flags in (capi.FLAG_IISPH_SELF_BY_SLOT, 0):
+        outs = []
+        for ref in (False, True):
+            for order in (None, perm):
+                s = capi.Solver(p, len(pos), solver=capi.IISPH, reference_order=ref, flags=flags)
+                s.set_particles(pos if order is None else pos[order], vel if order is None else vel[order])
+                s.set_boundaries(None, None, update_grid=True)
+                s.step(4)
+                gp, gv = s.download()
+                if flags and order is None:
+                    assert s.last_iterations == o.last_iters
+                    assert rel_err(gp[:, :3], o.get("pos")[:, :3]) <= TOL_STEPS
+                    assert rel_err(gv[:, :3], o.get("vel")[:, :3]) <= TOL_STEPS
+                outs.append(gp)
+                s.close()
+        np.testing.assert_array_equal(outs[0], outs[2])   # list-driven chain == reference-order kernels, bit for bit
+        d, idx = cKDTree(outs[0][:, :3]).query(outs[1][:, :3])
+        spread[flags] = float(d.max())
+    assert spread[capi.FLAG_IISPH_SELF_BY_SLOT] < 1e-5 and spread[0] > 1e-3, spread
+
+
 def test_iisph_with_boundaries(hip_lib):
     p, sc = small_dam_break(solver=IISPH)
     o, s = make_pair(p, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], solver=IISPH)

@@ -238,3 +238,139 @@ def test_slab_rebalance_hip_engine(tmp_path, hip_lib):
     moved = _run(2, 12, True, tmp_path, skew=-3, rebalance_every=2)
     owned = np.stack(_run.owned)
     assert abs(int(owned[0, -1]) - int(owned[1, -1])) < abs(int(owned[0, 0]) - int(owned[1, 0])) and moved > 0
+
+
+# ---------------------------------------------------------------- IISPH over slabs
+IISPH_LATTICE = (22, 8, 8)
+
+
+def _iisph_scene():
+    """A compressed block (so that the pressure solve has work) under the IISPH constructor defaults: global 128^3 grid."""
+    from nereus_amd import scene
+    from nereus_amd.params import default_params
+
+    p = default_params(1)
+    h = float(p["interactionRadius"][0])
+    pos = scene.fluid_block(*IISPH_LATTICE, h, jitter=0.02, spacing=0.72 * h)
+    vel = np.zeros_like(pos)
+    vel[:, 0] = np.where((np.arange(len(pos)) // IISPH_LATTICE[2]) % 2 == 0, 1.5, -1.5).astype(np.float32)  # cross the cut
+    return p, pos, vel
+
+
+def _iisph_worker(rank, world, port, steps, use_hip, outdir, by_slot):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from nereus_amd import capi, slab
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, pos, vel = _iisph_scene()
+    ox, cs = float(p["worldOrigin"][0][0]), float(p["cellSize"][0][0])
+    cx = slab.cell_of(pos[:, 0], ox, cs)
+    cut = int(np.median(cx)) + 1
+    cuts = [slab.NO_CUT_LO, cut, slab.NO_CUT_HI]
+    mine = (cx >= cuts[rank]) & (cx < cuts[rank + 1])
+    halo = slab.IISPH_HALO_CELLS
+    if use_hip:
+        eng = slab.HipSlabEngine(p, 4 * len(pos), 2 * len(pos), cuts[rank], cuts[rank + 1], 0, halo=halo, iisph=True,
+                                 flags=capi.FLAG_IISPH_SELF_BY_SLOT if by_slot else 0)
+    else:
+        from tests.slab_check_engine import OracleSlabEngine
+
+        eng = OracleSlabEngine(p, 2 * len(pos), cuts[rank], cuts[rank + 1], halo=halo, iisph=True, self_by_slot=by_slot)
+    eng.load(pos[mine], vel[mine], None, None)
+    drv = slab.SlabDriver(eng, rank, world, stage_through_host=use_hip)
+    iters, moved = [], 0
+    for _ in range(steps):
+        drv.exchange()
+        moved += drv.last_counts[1] + drv.last_counts[3]
+        iters.append(drv.iisph_step())
+    drv.finish()
+    op, ov = eng.owned_state()
+    np.savez(os.path.join(outdir, "irank%d.npz" % rank), pos=op, vel=ov, iters=np.array(iters), moved=moved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _iisph_single(p, pos0, vel0, steps, by_slot):
+    from tests.oracle_lib import IISPH, Oracle
+
+    o = Oracle(p, solver=IISPH, self_by_slot=by_slot)
+    o.set_particles(pos0, vel0)
+    o.set_boundaries(None, None)
+    iters = []
+    for _ in range(steps):
+        o.step(1)
+        iters.append(o.last_iters)
+    return o.get("pos"), o.get("vel"), iters
+
+
+def _match(ref_pos, pos):
+    """both w components are overwritten by iisph_integrate, so no id survives a step: pair the particles by position
+    (lattice spacing 0.039 m); returns (distances, index into ref)"""
+    from scipy.spatial import cKDTree
+
+    return cKDTree(ref_pos[:, :3]).query(pos[:, :3])
+
+
+def _run_iisph(steps, use_hip, tmp_path, by_slot):
+    mp.spawn(_iisph_worker, args=(2, _free_port(), steps, use_hip, str(tmp_path), by_slot), nprocs=2, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "irank%d.npz" % r)) for r in range(2)]
+    pos = np.concatenate([q["pos"] for q in parts])
+    vel = np.concatenate([q["vel"] for q in parts])
+    p, pos0, vel0 = _iisph_scene()
+    assert len(pos) == len(pos0), "particles lost or duplicated by the exchange"
+    assert sum(int(q["moved"]) for q in parts) > 0
+    rp, rv, ref_iters = _iisph_single(p, pos0, vel0, steps, by_slot)
+    assert list(parts[0]["iters"]) == ref_iters == list(parts[1]["iters"])   # the global exit test, same count on every rank
+    d, idx = _match(rp, pos)
+    return pos, vel, rp, rv, d, idx
+
+
+def _check_order_independent(steps, use_hip, tmp_path):
+    """NRS_FLAG_IISPH_SELF_BY_SLOT (SURVEY Q5 off): the result no longer depends on the order of the arrays, so two slabs must
+    reproduce the single-domain oracle particle for particle — this is the test of the halo width, of the pressure carried in
+    vel.w and of the all-reduced exit test."""
+    from tests.common import rel_err
+
+    pos, vel, rp, rv, d, idx = _run_iisph(steps, use_hip, tmp_path, True)
+    assert len(np.unique(idx)) == len(pos) and d.max() < 1e-5
+    assert rel_err(pos[:, :3], rp[idx, :3]) <= 1e-5
+    assert rel_err(vel[:, :3], rv[idx, :3]) <= 1e-4
+
+
+def _check_reference_mode(steps, use_hip, tmp_path):
+    """Default flags = the reference's Q5 self-exclusion by thread id: its result depends on the ORDER of the input arrays, and a
+    slab's local order is not the single domain's.  The yardstick is the single-domain oracle run on a permutation of the same
+    particles: the slab run must not be further from the single-domain run than that permuted run is."""
+    pos, vel, rp, rv, d, idx = _run_iisph(steps, use_hip, tmp_path, False)
+    p, pos0, vel0 = _iisph_scene()
+    perm = np.random.default_rng(1).permutation(len(pos0))
+    pp, _, _ = _iisph_single(p, pos0[perm], vel0[perm], steps, False)
+    dy, _ = _match(rp, pp)
+    print("IISPH, reference self-exclusion: slabs vs single domain max %.3e m (rms %.3e); permuted single domain max %.3e m (rms %.3e)"
+          % (d.max(), np.sqrt((d * d).mean()), dy.max(), np.sqrt((dy * dy).mean())))
+    assert dy.max() > 1e-3, "the yardstick itself: a permutation alone must move particles by millimetres"
+    assert d.max() <= 1.5 * dy.max() and np.sqrt((d * d).mean()) <= 1.5 * np.sqrt((dy * dy).mean())
+
+
+def test_iisph_slabs_gloo_cpu(tmp_path):
+    """IISPH over two slabs with the checker engine: 8-cell halo, pressure carried in vel.w, solver loop exit decided on the
+    all-reduced density error — against the single-domain oracle."""
+    _check_order_independent(4, False, tmp_path)
+
+
+def test_iisph_slabs_reference_mode_gloo_cpu(tmp_path):
+    _check_reference_mode(4, False, tmp_path)
+
+
+@pytest.mark.gpu
+def test_iisph_slabs_hip_engine(tmp_path, hip_lib):
+    _check_order_independent(6, True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_iisph_slabs_reference_mode_hip_engine(tmp_path, hip_lib):
+    _check_reference_mode(6, True, tmp_path)
