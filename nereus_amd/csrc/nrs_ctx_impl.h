@@ -81,7 +81,26 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             P.gridSize[0] = winW;
             P.numCells = winW * PU.gridSize[1] * PU.gridSize[2];
         }
+        // compact scan candidates (nrs_math.h): quanta per metre, threshold of the superset test, and whether the geometry allows
+        // it at all (a pair inside the interaction radius must be less than two cells apart on every axis)
+        float hq = 0.0f;
+        qOk = NRS_COMPACT_SCAN != 0 && P.gridSize[0] >= 4u; // (narrower grids alias the row's three cells: tags by position fail)
+        for (int a = 0; a < 3; ++a) {
+            qc.o[a] = (double)P.worldOrigin[a];
+            qc.s[a] = QP_PER_CELL / (float)P.cellSize[a];
+            const float r = (float)P.interactionRadius * qc.s[a];
+            qOk = qOk && P.cellSize[a] > (R)0 && std::isfinite(qc.s[a]) && (r + QP_MARGIN < QP_HALF);
+            hq = std::max(hq, r);
+        }
+        const double lim = (double)hq + (double)QP_MARGIN;
+        qT = qOk ? (uint32_t)std::ceil(lim * lim) + 1u : 0u;
     }
+    QuantCfg qc;
+    uint32_t qT = 0;
+    bool qOk = false;
+    DevBuf qpos; // two words per sorted slot (+ 4 slots of padding), written by the reorder kernels
+    // hit lists are built (and the kernels that consume them used) only when the scan that builds them can run
+    bool lists_ok() const { return hitBuf.p != nullptr && (NRS_COMPACT_SCAN == 0 || (qOk && qpos.p != nullptr)); }
     nrs_config cfg;
     uint64_t cap = 0, n = 0, nb = 0;
     bool midStep = false; // a partial step left the state mid-update
@@ -108,7 +127,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool deferWalls() const
     {
         static const bool allow = !(getenv("NEREUS_WALL_PASS") && atoi(getenv("NEREUS_WALL_PASS")) == 0);
-        return allow && nearBitsValid && nb != 0 && !iisph() && !refOrder() && hitBuf.p != nullptr;
+        return allow && nearBitsValid && nb != 0 && !iisph() && !refOrder() && lists_ok();
     }
     WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1}; }
     // this step's wall list: tile counts (reorder kernel) -> two-level scan (the re-sort's scan kernel) -> stable compaction
@@ -134,13 +153,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         static const int mode = getenv("NEREUS_STAGED") ? atoi(getenv("NEREUS_STAGED")) : -1;
         if (mode == 0 || !std::is_same<R, float>::value || iisph() || refOrder() || P.numCells > (1u << 30)) return false;
-        return mode == 1 || ((cfg.flags & NRS_FLAG_FAST_ARITH) && KSET == KS_MULLER && hitBuf.p != nullptr);
+        return mode == 1 || ((cfg.flags & NRS_FLAG_FAST_ARITH) && KSET == KS_MULLER && lists_ok());
     }
     // fast arithmetic (reciprocals, rsq, fused multiply-adds, density summed in the scan): fp32 Muller SESPH on the
     // production kernels with shared lists; everything else keeps the reference-order IEEE arithmetic
     bool fastArith() const
     {
-        return (cfg.flags & NRS_FLAG_FAST_ARITH) && std::is_same<R, float>::value && KSET == KS_MULLER && stagedScan() && hitBuf.p != nullptr;
+        return (cfg.flags & NRS_FLAG_FAST_ARITH) && std::is_same<R, float>::value && KSET == KS_MULLER && stagedScan() && lists_ok();
     }
     // coherent re-sort (nrs_kernels_resort.h)
     DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars, rsPrevPacked;
@@ -257,7 +276,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &fastQ, &nearBits, &wallList, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &qpos, &fastQ, &nearBits, &wallList, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -316,6 +335,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if ((!iisph() || KSET == KS_MULLER) && !(cfg.flags & (NRS_FLAG_REFERENCE_ORDER | NRS_FLAG_NO_SHARED_LISTS))) {
             NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
             NRSCHK(hitCounts.alloc((size_t)cap * 4));
+            if (NRS_COMPACT_SCAN) NRSCHK(qpos.alloc(((size_t)cap + 4) * QP_BYTES));
             if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
                 NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
@@ -591,6 +611,9 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         G.actHi = INT_MAX;
         G.nSorted = (uint32_t)n;
         G.err = errWord.as<uint32_t>();
+        G.qpos = lists_ok() ? qpos.as<qword_t>() : (const qword_t *)nullptr;
+        G.qT = qT;
+        G.qc = qc;
         return G;
     }
     IisphArrays<R> iisph_view() const
@@ -684,12 +707,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                                cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
-                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>());
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), qc,
+                               lists_ok() ? qpos.as<qword_t>() : (qword_t *)nullptr);
         else
             hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                                cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
-                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>());
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), qc,
+                               lists_ok() ? qpos.as<qword_t>() : (qword_t *)nullptr);
         if (iisph() && (cfg.flags & NRS_FLAG_IISPH_SELF_BY_SLOT)) // Q5 off: the pressure kernels skip j == own slot
             hipLaunchKernelGGL(k_identity, g, b, 0, stream, inv.as<uint32_t>(), N);
         NRSCHK(ev_end());
@@ -765,7 +790,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slabOn) { G.actLo = slab.lo - 1; G.actHi = slab.hi + 1; } // density is also needed one cell beyond the cuts
         // the density kernel's hit lists are handed to the force kernel when both run in this call
         HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
-        const bool share = !refOrder() && hitBuf.p && stop != NRS_STAGE_DENSITY;
+        const bool share = !refOrder() && lists_ok() && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         const bool fast = fastArith() && share && fastQ.p;
         if (HAS_B && share && wallListed && !refOrder()) NRSCHK(build_wall_list(N));
@@ -898,7 +923,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     //      every solver iteration, on the sum over ALL ranks: nrs_iisph_predict / _iterate / _finish) -----------------------------
     uint32_t iisphIter = 0;  // solver iterations done in the current step
     int iisphPhase = 0;      // 0 idle, 1 predicted (iterations may follow)
-    bool iisph_lists() const { return !refOrder() && hitBuf.p != nullptr && KSET == KS_MULLER; }
+    bool iisph_lists() const { return !refOrder() && lists_ok() && KSET == KS_MULLER; }
 
     // predictAdvection (sph_cuda.cu:513-697)
     template <bool HAS_B> int iisph_predict(int stop)

@@ -27,6 +27,11 @@ template <typename R> struct GridView {
     // NRS_E_STATE at the next nrs_synchronize / nrs_download instead of the device faulting.
     uint32_t nSorted;
     uint32_t *err;
+    // compact scan candidates (nrs_math.h, quantize_pos): one word per sorted slot, written by the reorder kernels; qT = integer
+    // squared-distance threshold of the superset test; null = this context scans the exact positions
+    const qword_t *qpos;
+    uint32_t qT;
+    QuantCfg qc;
 };
 template <typename R> NRS_DEV bool run_ok(const GridView<R> &G, uint32_t a, uint32_t b)
 {
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
                                                    typename Vec4T<R>::type *__restrict__ sVel, R *__restrict__ sPres,
                                                    uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
                                                    uint32_t *__restrict__ inv, uint32_t n,
-                                                   const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount)
+                                                   const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount,
+                                                   QuantCfg qc, qword_t *__restrict__ qpos)
 {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? hash[i] : 0u, i < n);
@@ -101,7 +107,9 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
     }
     if (i == n - 1) cellEnd[h] = n;
     const uint32_t src = index[i];
-    sPos[i] = oldPos[src];
+    const typename Vec4T<R>::type p4 = oldPos[src];
+    sPos[i] = p4;
+    if (qpos) qpos[i] = quantize_pos<R>(qc, xyz<R>(p4));
     sVel[i] = oldVel[src];
     if (oldPres) sPres[i] = oldPres[src];
     if (inv) inv[src] = i;

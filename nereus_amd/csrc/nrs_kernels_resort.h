@@ -172,7 +172,8 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__rest
                                                           typename Vec4T<R>::type *__restrict__ sVel, R *__restrict__ sPres,
                                                           uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
                                                           uint32_t *__restrict__ inv, uint32_t n,
-                                                          const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount)
+                                                          const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount,
+                                                          QuantCfg qc, qword_t *__restrict__ qpos)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? (uint32_t)(merged[i] >> 32) : 0u, i < n);
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__rest
     if (i == n - 1) cellEnd[h] = n;
     hashOut[i] = h;
     indexOut[i] = src;
-    sPos[i] = oldPos[src];
+    const typename Vec4T<R>::type p4 = oldPos[src];
+    sPos[i] = p4;
+    if (qpos) qpos[i] = quantize_pos<R>(qc, xyz<R>(p4));
     sVel[i] = oldVel[src];
     if (oldPres) sPres[i] = oldPres[src];
     if (inv) inv[src] = i;

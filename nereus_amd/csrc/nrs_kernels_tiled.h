@@ -59,6 +59,16 @@ NRS_DEV double bcast_lane(double v, int srcLane)
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srcLane), hi = __builtin_amdgcn_readlane((int)(b >> 32), srcLane);
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
 }
+#ifndef NRS_COMPACT_SCAN
+#define NRS_COMPACT_SCAN 1 // interior workgroups scan the 4-byte quantised candidates (Sweep::scan_compact); 0: the exact positions
+#endif
+#ifndef QP_WALK
+#define QP_WALK 4 // list entries whose exact positions are gathered together in density_from_superset
+#endif
+#ifndef QP_PRE
+#define QP_PRE 2 // (4: 104 VGPRs unbounded, 5 dwords spilled at the 80-VGPR bound, 0.649 vs 0.583 ms) dwordx4 candidate loads (two candidates each) per row issued before the first test (x 3 rows of a z-plane)
+#endif
+constexpr int SCAN_CAP = 21; // list entries the compact scan can hold: HIT_CAP + the particle itself (+ 3 spill rows behind them)
 constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (6: 79 VGPRs = 6 waves, 0.81 vs 0.71 ms; 8: slower still)
 
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
@@ -198,6 +208,133 @@ template <typename R> struct Sweep {
         hc.nf = nf; hc.nb = nb; hc.over = over; hc.anyB = anyB;
         return hc;
     }
+
+    // ---- compact scan (interior code: no boundary particles) ---------------------------------------------------------------
+    // Same walk as scan() — z-plane by z-plane, the three x-cells of a row as one run — but the candidates are the 8-byte words
+    // of G.qpos (nrs_math.h, quantize_pos) and the test is an integer squared distance against G.qT (two v_pk_sub_i16 + two
+    // v_dot2_i32_i16): the list is a SUPERSET of the exact hits (< 1 % more entries), in the visiting order.  Two candidates
+    // travel per global_load_dwordx4, and the first QP_PRE loads of all three rows of a plane are issued together before the
+    // first test; a load may run one slot past the end of its row (masked by q < nT; the array is padded).
+    // The append is BRANCH-FREE: every slot stores its entry at the thread's write cursor and the cursor advances only on a hit,
+    // so a miss is overwritten by the next slot (rows SCAN_CAP .. SCAN_CAP + 2 of the LDS array are the spill rows of a full
+    // list).  In a wavefront some lane hits at almost every slot, so a branchy append ran its body ~70 times per wave anyway,
+    // plus the exec-mask bookkeeping.  An entry carries the ROW number only (tag = 3 * row); which of the row's three cells the
+    // candidate sits in — the reference's summation order needs it — is decided in density_from_superset() from the exact
+    // position, once per HIT instead of once per slot; the particle itself is dropped there too (it costs one list slot here:
+    // SCAN_CAP = HIT_CAP + 1).
+    typedef short qs2 __attribute__((ext_vector_type(2)));
+    static constexpr int QSLOTS = 16 / QP_BYTES; // candidates per global_load_dwordx4
+    struct __attribute__((packed, aligned(QP_BYTES))) Q2 { uint32_t v[4]; };
+    static NRS_DEV Q2 ldq(const qword_t *__restrict__ qpos, uint32_t idx)
+    {
+        return *reinterpret_cast<const Q2 *>(reinterpret_cast<const char *>(qpos) + idx * (uint32_t)QP_BYTES);
+    }
+    template <int W>
+    static NRS_DEV HitCounts scan_compact(const Params<R> &P, const GridView<R> &G, V3<R> p, uint32_t (*lst)[W])
+    {
+        const I3 gp = calcGridPos<R>(P, p);
+        const uint32_t mx = P.gridSize[0] - 1, my = P.gridSize[1] - 1, mz = P.gridSize[2] - 1;
+        const uint32_t cx = grid_x<R>(P, gp.x);
+        const uint32_t x0 = (cx - 1u) & mx, x2 = (cx + 1u) & mx;
+        const bool contiguous = (cx >= 1u) && (cx + 1u <= mx);
+        float tx, ty, tz;
+        quantize_t<R>(G.qc, p, tx, ty, tz);
+        // an owner too far from the grid origin for the error budget of the quanta (or with a NaN coordinate) is served by the
+        // reference-order walk, like a list overflow
+        const bool far = !((fabsf(tx) < QP_FAR) & (fabsf(ty) < QP_FAR) & (fabsf(tz) < QP_FAR));
+        const qword_t Qw = pack_quanta(tx, ty, tz);
+#if QP_BYTES == 8
+        const qs2 Qxy = __builtin_bit_cast(qs2, Qw.x), Qz = __builtin_bit_cast(qs2, Qw.y);
+#else
+        const uint32_t Qi = Qw | QP_GUARD;
+#endif
+        const uint32_t qT = G.qT;
+        const qword_t *__restrict__ qpos = G.qpos;
+        // write cursor: byte offset of lst[nf][tid] from lst[0][0]
+        // (the clamp sits one row BEHIND the last valid row, so that a cursor that ever passed SCAN_CAP entries stays there: sticky overflow)
+        const uint32_t col = threadIdx.x * 4u, rowBytes = (uint32_t)W * 4u, capOff = col + (uint32_t)(SCAN_CAP + 1) * rowBytes;
+        uint32_t cur = col;
+        char *const lbase = reinterpret_cast<char *>(&lst[0][0]);
+
+        // candidates a + base .. a + base + QSLOTS - 1 of a run of nT slots; aTag = a | (3 * row) << HIT_TAG_SHIFT
+        auto test2 = [&](const Q2 &c, uint32_t aTag, uint32_t base, uint32_t nT) {
+#pragma unroll
+            for (int u = 0; u < QSLOTS; ++u) {
+                if ((u & 1) == 0) cur = min(cur, capOff);
+#if QP_BYTES == 8
+                const qs2 dxy = Qxy - __builtin_bit_cast(qs2, c.v[2 * u]), dz = Qz - __builtin_bit_cast(qs2, c.v[2 * u + 1]);
+                const uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(dz, dz, __builtin_amdgcn_sdot2(dxy, dxy, 0, false), false);
+#else
+                const uint32_t t = Qi - c.v[u];
+                const int dx = ((int)(t << 22)) >> 22, dy = ((int)(t << 11)) >> 22, dz = ((int)t) >> 22;
+                const uint32_t d2 = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz));
+#endif
+                const uint32_t q = base + (uint32_t)u;
+                const bool hit = (d2 < qT) & (q < nT);
+#if !defined(NRS_ABL_NOAPPEND)
+                *reinterpret_cast<uint32_t *>(lbase + cur) = aTag + q;
+#endif
+                cur += hit ? rowBytes : 0u;
+            }
+        };
+        auto sweepRun = [&](uint32_t aTag, uint32_t nT, uint32_t from) {
+            for (uint32_t base = from; base < nT; base += QSLOTS) test2(ldq(qpos, (aTag & HIT_INDEX) + base), aTag, base, nT);
+        };
+
+        for (int z = -1; z <= 1; z++) {
+            const uint32_t cz = (uint32_t)(gp.z + z) & mz;
+            const uint32_t plane = umul24(umul24(cz, P.gridSize[1]), P.gridSize[0]);
+            uint32_t st[3][3], en[3][3];
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const uint32_t cy = (uint32_t)(gp.y + y - 1) & my;
+                const uint32_t hrow = plane + umul24(cy, P.gridSize[0]);
+                const uint32_t h[3] = {hrow + x0, hrow + cx, hrow + x2};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    st[y][c] = G.cellStart[h[c]];
+                    en[y][c] = G.cellEnd[h[c]];
+                }
+            }
+            if (contiguous) {
+                uint32_t lo[3], nT[3];
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const uint32_t s0 = st[y][0], s1 = st[y][1], s2 = st[y][2];
+                    uint32_t a = (s0 != CELL_EMPTY) ? s0 : ((s1 != CELL_EMPTY) ? s1 : s2);
+                    uint32_t b = (s2 != CELL_EMPTY) ? en[y][2] : ((s1 != CELL_EMPTY) ? en[y][1] : en[y][0]);
+                    if (a == CELL_EMPTY) a = b = 0;
+                    lo[y] = a;
+                    nT[y] = run_ok<R>(G, a, b) ? b - a : 0u;
+                }
+                Q2 c[3][QP_PRE];
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+#pragma unroll
+                    for (int k = 0; k < QP_PRE; ++k) c[y][k] = ldq(qpos, lo[y] + min((uint32_t)(QSLOTS * k), nT[y]));
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const uint32_t aTag = lo[y] | ((uint32_t)((z + 1) * 9 + y * 3) << HIT_TAG_SHIFT);
+#pragma unroll
+                    for (int k = 0; k < QP_PRE; ++k)
+                        if (k == 0 || nT[y] > (uint32_t)(QSLOTS * k)) // (rows of neighbouring lanes are alike: a whole wave often skips this)
+                            test2(c[y][k], aTag, (uint32_t)(QSLOTS * k), nT[y]);
+                    sweepRun(aTag, nT[y], (uint32_t)(QSLOTS * QP_PRE));
+                }
+            } else { // the 3-cell window wraps around the grid edge: cell by cell, in the reference's order
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (st[y][c] != CELL_EMPTY && run_ok<R>(G, st[y][c], en[y][c]))
+                            sweepRun(st[y][c] | ((uint32_t)((z + 1) * 9 + y * 3) << HIT_TAG_SHIFT), en[y][c] - st[y][c], 0u);
+            }
+        }
+        const uint32_t nf = (cur - col) / rowBytes;
+        HitCounts hc;
+        hc.nf = (int)nf; hc.nb = 0; hc.over = far || nf > (uint32_t)SCAN_CAP; hc.anyB = false;
+        return hc;
+    }
 };
 
 // Merge cursor over the two hit lists: yields hits in the reference's order (cell 0 fluid, cell 0 boundary,
@@ -270,6 +407,52 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
         }
     }
     d += part;
+    return d;
+}
+
+// Process phase behind Sweep::scan_compact (no boundary list): the exact cut-off of the list (`dot(r,r) < tKeep`, the test scan()
+// applies to its candidates) on the exact position, which the density sum needs anyway.  A survivor gets its full cell tag here
+// — 3 * row (from the scan) + the cell's place in the row, from calcGridPos's own expression on the candidate's exact x — and is
+// written back to the front of the thread's LDS column (w <= k): what is published afterwards is exactly the list scan() would
+// have produced, and the sums are formed in the same order (one partial sum per cell).
+template <typename R, int KSET, bool STRICT>
+NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::type *__restrict__ sPos, V3<R> p, uint32_t (*lst)[BLOCK],
+                                int &nf, float tKeep, uint32_t self)
+{
+    const uint32_t tid = threadIdx.x;
+    const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass;
+    const uint32_t mx = P.gridSize[0] - 1;
+    const int gxi = (int)floor((p.x - P.worldOrigin[0]) / P.cellSize[0]);
+    R d = (R)0.0;
+    d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
+    R part = (R)0.0;
+    uint32_t prevTag = 0xffffffffu;
+    int w = 0;
+    // the exact positions of QP_WALK entries are requested together (the entries are independent; a plain loop exposes one
+    // memory round trip per entry)
+    for (int k0 = 0; k0 < nf; k0 += QP_WALK) {
+        uint32_t e[QP_WALK];
+        V3<R> q[QP_WALK];
+#pragma unroll
+        for (int u = 0; u < QP_WALK; ++u) e[u] = lst[min(k0 + u, nf - 1)][tid];
+#pragma unroll
+        for (int u = 0; u < QP_WALK; ++u) q[u] = xyz<R>(sPos[e[u] & HIT_INDEX]);
+#pragma unroll
+        for (int u = 0; u < QP_WALK; ++u) {
+            const V3<R> r = p - q[u];
+            const uint32_t j = e[u] & HIT_INDEX;
+            if ((k0 + u < nf) && (dot(r, r) < tKeep) && (STRICT || j != self)) { // (STRICT: the wide IISPH list keeps the particle itself)
+                const int gxj = (int)floor((q[u].x - P.worldOrigin[0]) / P.cellSize[0]);
+                const uint32_t tag = (e[u] >> HIT_TAG_SHIFT) + (((uint32_t)(gxj - gxi) + 1u) & mx);
+                lst[min(w, HIT_CAP - 1)][tid] = j | (tag << HIT_TAG_SHIFT);
+                ++w;
+                if (tag != prevTag) { d += part; part = (R)0.0; prevTag = tag; }
+                if (!STRICT || ((j != self) && (length(r) < ir))) part += (pm * W_dens<R, KSET>(r, ir, kp));
+            }
+        }
+    }
+    d += part;
+    nf = w;
     return d;
 }
 
@@ -484,10 +667,30 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
 {
     const uint32_t tid = threadIdx.x;
     constexpr int BF = SHARE ? (KSET == KS_MULLER ? 1 : 2) : 0;
-    const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK, WIDE>(P, G, thr, sPos, WIDE ? 0xffffffffu : i, p, lst);
+    constexpr bool COMPACT = NRS_COMPACT_SCAN && !HAS_B && SHARE; // (the context publishes lists only when its qpos array is valid)
+    HitCounts hc;
     R d;
-    if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
-    else d = density_from_hits<R, KSET, HAS_B, WIDE>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
+    if constexpr (COMPACT) {
+#if defined(NRS_ABL_NOSCAN) // timing ablations (tools/density_ablate2.py): results are wrong by design
+        hc.nf = 0; hc.nb = 0; hc.over = false; hc.anyB = false;
+#else
+        hc = Sweep<R>::template scan_compact<BLOCK>(P, G, p, lst);
+#endif
+#if defined(NRS_ABL_NOPROCESS)
+        d = (R)hc.nf;
+        hc.nf = 0; hc.over = false; // (publish empty lists: the entries carry row tags only)
+#else
+        if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow / far owner: reference-order path
+        else {
+            d = density_from_superset<R, KSET, WIDE>(P, sPos, p, lst, hc.nf, WIDE ? thr.r2LeH2 : thr.lenLtIr, i);
+            if (hc.nf > HIT_CAP) { hc.over = true; d = density_of<R, KSET, HAS_B>(P, G, sPos, i); } // (only when the list held HIT_CAP + 1 exact hits)
+        }
+#endif
+    } else {
+        hc = Sweep<R>::template scan<HAS_B, BF, BLOCK, WIDE>(P, G, thr, sPos, WIDE ? 0xffffffffu : i, p, lst);
+        if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
+        else d = density_from_hits<R, KSET, HAS_B, WIDE>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
+    }
     dens[i] = d;
     if (pres) pres[i] = tait_pressure<R>(P, d);
     if (SHARE) {
@@ -505,12 +708,12 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
 #define DENSITY_DEFER_MIN_WAVES 6 // waves/SIMD the two-kinds-of-workgroups kernel is register-bounded for: unbounded 84 VGPRs (5 waves) 0.677 ms, 6 (80 VGPRs, 3 dwords spilled) 0.650, 7 (72, 11 spilled) 0.651
 #endif
 template <typename R, int KSET, bool HAS_B, bool SHARE, bool WIDE = false, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, ((DEFER && sizeof(R) == 4) ? DENSITY_DEFER_MIN_WAVES : 1)) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
+__global__ __launch_bounds__(BLOCK, (((DEFER || (NRS_COMPACT_SCAN && !HAS_B && SHARE)) && sizeof(R) == 4) ? DENSITY_DEFER_MIN_WAVES : 1)) void k_density_tiled(Params<R> P, GridView<R> G, CutThresholds thr,
                                                          const typename Vec4T<R>::type *__restrict__ sPos,
                                                          R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
                                                          uint32_t n, WallList wl, uint32_t wallBlocks)
 {
-    __shared__ uint32_t lst[HIT_CAP][BLOCK];
+    __shared__ uint32_t lst[SCAN_CAP + 3][BLOCK]; // (rows SCAN_CAP .. SCAN_CAP + 2: spill rows of the branch-free append, Sweep::scan_compact)
     uint32_t block = blockIdx.x, blocks = gridDim.x;
     if (DEFER) {
         if (block < wallBlocks) {
