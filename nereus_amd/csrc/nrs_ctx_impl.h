@@ -6,6 +6,7 @@
 // "unsorted" arrays of step t+1 are the integrated sorted arrays of step t (buffer swap), which is what
 // the reference obtains by copying sorted→host→device.
 #pragma once
+#include <sched.h>
 #include "nrs_ctx_base.h"
 #include <rocprim/rocprim.hpp>
 
@@ -1387,6 +1388,9 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             for (uint64_t spins = 0;; ++spins) {
                 const uint64_t v = *w;
                 if ((uint32_t)(v >> 32) == rsSeq) { *M = (uint32_t)v; return NRS_OK; }
+                // polite spin: on a host with fewer free cores than ranks (8 ranks on a 16-CPU share) the poller hands its
+                // time slice to whoever is runnable; with an idle core the yield returns at once and costs no latency
+                if ((spins & 63u) == 63u) sched_yield();
                 if ((spins & 0xfffff) == 0xfffff) { // every ~1 M polls: has the stream failed or finished without us seeing it?
                     const hipError_t e = hipEventQuery(rsEvent);
                     if (e == hipSuccess) break;

@@ -6,8 +6,11 @@
 // it.  Selected with NRS_FLAG_REFERENCE_ORDER; used for bit-level comparison with the oracle and as the
 // semantic definition the tiled kernels (nrs_kernels_tiled.h) are checked against.
 //
-// What each kernel computes is specified by the reference kernel cited above it; none of the reference's
-// source is reproduced here.
+// What each kernel computes is specified by the reference kernel cited above it.  The physics statements of the force /
+// density / IISPH loops (and the smoothing kernels of nrs_math.h) are restatements of the reference's expressions IN THE
+// REFERENCE'S EVALUATION ORDER, with its operand names where that helps checking them line by line: the parity goal
+// (every float sum bit-identical to the reference's arithmetic) forces the expression order; everything around them —
+// thread mapping, memory layout, templates, boundary packing, double-buffered P_l — is this build's own.
 #pragma once
 #include "nrs_math.h"
 

@@ -174,6 +174,9 @@ template <typename R> struct Sweep {
                 }
             }
             if (HAS_B) {
+#if defined(NRS_ABL_NOBSWEEP) // timing ablation: boundary cells are not swept
+                bmask = 0u;
+#endif
                 anyB = anyB || bmask != 0u;
                 // boundary cells of this plane, visited in ascending cell number by the lanes that have any
                 // (a wave-cooperative sweep — one wall lane at a time, 64 candidates per round, hits ranked with a ballot — was
@@ -222,6 +225,8 @@ template <typename R> struct Sweep {
     // candidate sits in — the reference's summation order needs it — is decided in density_from_superset() from the exact
     // position, once per HIT instead of once per slot; the particle itself is dropped there too (it costs one list slot here:
     // SCAN_CAP = HIT_CAP + 1).
+    // (Measured and dropped: skipping the corner rows the owner cannot reach geometrically — the lanes of a wave rarely agree, 0.538
+    // vs 0.546 ms at rest, 0.915 vs 0.910 developed.)
     typedef short qs2 __attribute__((ext_vector_type(2)));
     static constexpr int QSLOTS = 16 / QP_BYTES; // candidates per global_load_dwordx4
     struct __attribute__((packed, aligned(QP_BYTES))) Q2 { uint32_t v[4]; };
@@ -442,8 +447,12 @@ NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::typ
             const V3<R> r = p - q[u];
             const uint32_t j = e[u] & HIT_INDEX;
             if ((k0 + u < nf) && (dot(r, r) < tKeep) && (STRICT || j != self)) { // (STRICT: the wide IISPH list keeps the particle itself)
+#if defined(NRS_ABL_NODIV) // timing ablation: row tags only (summation order within a row is then not the reference's)
+                const uint32_t tag = (e[u] >> HIT_TAG_SHIFT);
+#else
                 const int gxj = (int)floor((q[u].x - P.worldOrigin[0]) / P.cellSize[0]);
                 const uint32_t tag = (e[u] >> HIT_TAG_SHIFT) + (((uint32_t)(gxj - gxi) + 1u) & mx);
+#endif
                 lst[min(w, HIT_CAP - 1)][tid] = j | (tag << HIT_TAG_SHIFT);
                 ++w;
                 if (tag != prevTag) { d += part; part = (R)0.0; prevTag = tag; }
@@ -721,7 +730,11 @@ __global__ __launch_bounds__(BLOCK, (((DEFER || (NRS_COMPACT_SCAN && !HAS_B && S
             for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK) {
                 const uint32_t i = wl.list[t];
                 const V3<R> p = xyz<R>(sPos[i]);
+#if defined(NRS_ABL_NOWALL) // timing ablation: wall particles get no work at all
+                if (true) {
+#else
                 if (!slab_active<R>(P, G, p.x)) {
+#endif
                     dens[i] = (R)0;
                     if (pres) pres[i] = (R)0;
                     hb.counts[i] = COUNTS_DEFERRED;

@@ -384,6 +384,54 @@ def test_crowded_cell_overflow_path_and_wrap(hip_lib):
         assert rel_err(s.get("forces"), o.get("forces")) <= 10 * TOL_STAGE
 
 
+def test_compact_scan_guards(hip_lib):
+    """The quantised neighbour scan (nrs_math.h quantize_pos, Sweep::scan_compact) and its ways out: owners further from the
+    grid origin than the quanta's error budget covers (2^20 quanta = 4096 cells: reference-order walk for those lanes), NaN
+    positions, a cell size the modulo-4-cells trick cannot serve (h > 1.99 cellSize: the context builds no lists at all), and a
+    grid narrower than four cells in x (tags by position would alias)."""
+    base = Oracle.default_params(SESPH)
+    h = float(base["interactionRadius"][0])
+    rng = np.random.default_rng(23)
+
+    def cloud(centre, n, spread):
+        a = np.ones((n, 4), np.float32)
+        a[:, :3] = (np.asarray(centre) + rng.uniform(-spread * h, spread * h, (n, 3))).astype(np.float32)
+        return a
+
+    near = cloud([0.2, 0.1, -0.3], 400, 2.5)
+    far_out = cloud([-1.1 + 5000.3 * h, 0.3, 0.2], 60, 1.2)     # ~5000 cells from the grid origin in x: beyond QP_FAR
+    edge_far = cloud([-1.1 + 4095.6 * h, -0.2, 0.1], 80, 1.0)   # straddles the 4096-cell limit
+    cases = []
+    pos = np.concatenate([near, far_out, edge_far])
+    cases.append(("far owners", base, pos))
+    nanpos = np.concatenate([near, cloud([0.5, 0.5, 0.5], 30, 1.0)])
+    nanpos[5, 0] = np.nan
+    nanpos[410, 2] = np.nan   # (not inf: float -> int conversion of inf saturates differently on the host and the device)
+    cases.append(("nan positions", base, nanpos))
+    small = base.copy()
+    small["cellSize"][0] = np.float32(0.45 * h)                  # h / cellSize = 2.2: pairs inside h may be > 2 cells apart
+    cases.append(("cell size 0.45 h", small, near))
+    narrow = base.copy()
+    narrow["gridSize"][0] = (2, 64, 64)
+    narrow["numCells"][0] = 2 * 64 * 64
+    cases.append(("grid two cells wide", narrow, near))
+    for name, p, pos in cases:
+        vel = np.zeros_like(pos)
+        o, s = make_pair(p, pos, vel)
+        o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
+        np.testing.assert_array_equal(s.get("hash"), o.get("hash"), err_msg=name)
+        np.testing.assert_array_equal(s.get("index"), o.get("index"), err_msg=name)
+        gd, od = s.get("dens"), o.get("dens")
+        fin = np.isfinite(od)
+        np.testing.assert_array_equal(np.isfinite(gd), fin, err_msg=name)
+        assert rel_err(gd[fin], od[fin]) <= TOL_STAGE, name
+        gf, of = s.get("forces")[:, :3], o.get("forces")[:, :3]
+        finf = np.isfinite(of).all(1)
+        np.testing.assert_array_equal(np.isfinite(gf).all(1), finf, err_msg=name)
+        assert rel_err(gf[finf], of[finf]) <= 10 * TOL_STAGE, name
+        s.close()
+
+
 def test_iisph_stages_and_steps(hip_lib):
     p, pos, vel = compressed_block()
     o, s = make_pair(p, pos, vel, solver=IISPH)
