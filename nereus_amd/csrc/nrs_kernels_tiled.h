@@ -62,6 +62,9 @@ NRS_DEV double bcast_lane(double v, int srcLane)
 #ifndef NRS_COMPACT_SCAN
 #define NRS_COMPACT_SCAN 1 // interior workgroups scan the 4-byte quantised candidates (Sweep::scan_compact); 0: the exact positions
 #endif
+#ifndef NRS_FORCE_PAIRS
+#define NRS_FORCE_PAIRS 1 // the list-driven force kernel gathers (p / rho^2, m / rho) pairs written by the density kernel (HitBuffer::pairs)
+#endif
 #ifndef QP_WALK
 #define QP_WALK 4 // list entries whose exact positions are gathered together in density_from_superset
 #endif
@@ -69,12 +72,20 @@ NRS_DEV double bcast_lane(double v, int srcLane)
 #define QP_PRE 2 // (4: 104 VGPRs unbounded, 5 dwords spilled at the 80-VGPR bound, 0.649 vs 0.583 ms) dwordx4 candidate loads (two candidates each) per row issued before the first test (x 3 rows of a z-plane)
 #endif
 constexpr int SCAN_CAP = 21; // list entries the compact scan can hold: HIT_CAP + the particle itself (+ 3 spill rows behind them)
+// a * b + c on 24-bit signed operands in ONE instruction (the compiler prefers three multiplies and a three-operand add)
+NRS_DEV int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memory round trip (6: 79 VGPRs = 6 waves, 0.81 vs 0.71 ms; 8: slower still)
 
 // Result of the scan phase: fluid hits are lst[0 .. nf) (ascending), boundary hits are
 // lst[HIT_CAP-1 .. HIT_CAP-nb] (descending slots, ascending visiting order); both lists are ordered by cell
 // number, so the process phase restores the reference's order (cell by cell: fluid, then boundary) by merging.
 struct HitCounts { int nf, nb; bool over; bool anyB; }; // anyB: some of the 27 cells holds boundary particles
+template <typename R> struct PrePair { R prq, mrho; }; // (p / rho^2, m / rho) of one sorted slot, see HitBuffer::pairs
 
 template <typename R> struct Sweep {
     typedef typename Vec4T<R>::type T4;
@@ -272,7 +283,7 @@ template <typename R> struct Sweep {
 #else
                 const uint32_t t = Qi - c.v[u];
                 const int dx = ((int)(t << 22)) >> 22, dy = ((int)(t << 11)) >> 22, dz = ((int)t) >> 22;
-                const uint32_t d2 = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz));
+                const uint32_t d2 = (uint32_t)mad24(dz, dz, mad24(dy, dy, __mul24(dx, dx)));
 #endif
                 const uint32_t q = base + (uint32_t)u;
                 const bool hit = (d2 < qT) & (q < nT);
@@ -297,8 +308,11 @@ template <typename R> struct Sweep {
                 const uint32_t h[3] = {hrow + x0, hrow + cx, hrow + x2};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    st[y][c] = G.cellStart[h[c]];
-                    en[y][c] = G.cellEnd[h[c]];
+                    // one 32-bit byte offset serves both tables (scalar base + vector offset form of global_load: no 64-bit
+                    // address arithmetic per entry); 4 * numCells <= 2^32 because a hash has at most 30 bits
+                    const uint32_t off = h[c] * 4u;
+                    st[y][c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(G.cellStart) + off);
+                    en[y][c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(G.cellEnd) + off);
                 }
             }
             if (contiguous) {
@@ -500,13 +514,13 @@ NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3
 }
 
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
-template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false>
+template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false, bool PAIRS = false>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sPos,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
                                      const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu,
-                                     const R *pre = nullptr)
+                                     const R *pre = nullptr, const PrePair<R> *__restrict__ pairs = nullptr)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -539,10 +553,17 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         } else {
             const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
             if (STRICT && ((j == self) || !(length(p1p2) < ir))) continue; // the loop's own tests (:494,:505)
-            const R dens2 = sDens[j];
-            const R pres2 = sPres[j];
+            R prq2, mrho2; // pres2 / (dens2 * dens2), m2 / dens2
+            if (PAIRS) {
+                const PrePair<R> q = pairs[j];
+                prq2 = q.prq; mrho2 = q.mrho;
+            } else {
+                const R dens2 = sDens[j];
+                const R pres2 = sPres[j];
+                const R d2sq = dens2 * dens2;
+                prq2 = pres2 / d2sq; mrho2 = m2 / dens2;
+            }
             const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
-            const R d2sq = dens2 * dens2;
             V3<R> kpressure_grad, kvisco_grad;
             R kernel;
             if (KSET == KS_MONAGHAN) {
@@ -554,10 +575,10 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                 kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
                 kernel = Wdefault<R>(p1p2, ir, kp);
             }
-            A.fpres = A.fpres + (m2 * (pres / d1sq + pres2 / d2sq) * kpressure_grad);
+            A.fpres = A.fpres + (m2 * (pres / d1sq + prq2) * kpressure_grad);
             const R a = dot(p1p2, kvisco_grad);
             const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
-            A.fvisc = A.fvisc + (m2 / dens2 * v1v2 * (a / b));
+            A.fvisc = A.fvisc + (mrho2 * v1v2 * (a / b));
             if (SURF) {
                 V3<R> ai = mk3<R>(0, 0, 0);
                 const R r2 = dot(p1p2, p1p2);
@@ -583,7 +604,10 @@ NRS_DEV uint32_t xcd_tile(uint32_t b, uint32_t nb)
 // Hit lists shared between the two gathers of a step: the density kernel scans once, uses the hits, and (when
 // `hb.hits` is set) leaves them in global memory for the force kernel, which then needs no scan and no LDS.
 // hits[k * stride + i] is particle i's k-th list slot (k-major ⇒ coalesced), counts[i] = nf | nb << 8 | over << 16.
-struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; };
+// pairs (SESPH): per sorted slot (p / rho^2, m / rho), formed ONCE by the density kernel with the operands and the divisions the
+// force loop would use for that neighbour (computeCellForces, sph_kernel_impl.cuh:531,541) — two IEEE divisions less per hit there,
+// one 8-byte gather instead of two 4-byte ones; bit-identical by construction.  null = the force loop divides itself.
+struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; void *pairs = nullptr; };
 NRS_DEV uint32_t pack_counts(HitCounts hc)
 {
     return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u) | (hc.anyB ? 1u << 17 : 0u);
@@ -701,7 +725,16 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
         else d = density_from_hits<R, KSET, HAS_B, WIDE>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
     }
     dens[i] = d;
-    if (pres) pres[i] = tait_pressure<R>(P, d);
+    if (pres) {
+        const R pr = tait_pressure<R>(P, d);
+        pres[i] = pr;
+        if (SHARE && hb.pairs) {
+            PrePair<R> q;
+            q.prq = pr / (d * d);
+            q.mrho = P.particleMass / d;
+            reinterpret_cast<PrePair<R> *>(hb.pairs)[i] = q;
+        }
+    }
     if (SHARE) {
         hb.counts[i] = pack_counts(hc) | countFlags;
         if (!hc.over) {
@@ -861,7 +894,9 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
         const R dens = sDens[i], pres = sPres[i];
         ForceAcc<R> A;
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride, hc);
+        else // (the context hands out lists only together with the pairs array of the same density launch)
+            A = forces_from_hits<R, KSET, SURF, HAS_B, false, NRS_FORCE_PAIRS != 0>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride,
+                                                                                     hc, 0xffffffffu, nullptr, reinterpret_cast<const PrePair<R> *>(hb.pairs));
         f = sesph_total_force<R>(P, A, dens);
     }
     forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
