@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured-achievable)
-TRAFFIC_PROFILE = "r02_ns10M_resting_hbm_traffic.json"  # committed rocprofv3 PMC summary the `traffic` field is read from
+TRAFFIC_PROFILE = "r02b_ns10M_resting_hbm_traffic.json"  # committed rocprofv3 PMC summary the `traffic` field is read from
 
 
 
