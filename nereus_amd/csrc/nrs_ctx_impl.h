@@ -129,7 +129,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool deferWalls() const
     {
         static const bool allow = !(getenv("NEREUS_WALL_PASS") && atoi(getenv("NEREUS_WALL_PASS")) == 0);
-        return allow && nearBitsValid && nb != 0 && !iisph() && !refOrder() && lists_ok();
+        return allow && nearBitsValid && nb != 0 && (!iisph() || iisph_lists()) && !refOrder() && lists_ok();
     }
     WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1}; }
     // this step's wall list: tile counts (reorder kernel) -> two-level scan (the re-sort's scan kernel) -> stable compaction
@@ -496,7 +496,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                            dBi.as<T4>(), dVbi.as<R>(), bSorted.as<T4>(), bCellStart.as<uint32_t>(),
                            bCellEnd.as<uint32_t>(), (uint32_t)nb);
         nearBitsValid = false;
-        if (!iisph() && is_pow2(P.gridSize[0]) && is_pow2(P.gridSize[1]) && is_pow2(P.gridSize[2])) {
+        if ((!iisph() || KSET == KS_MULLER) && is_pow2(P.gridSize[0]) && is_pow2(P.gridSize[1]) && is_pow2(P.gridSize[2])) {
             const size_t words = ((size_t)P.numCells + 31) / 32;
             NRSCHK(nearBits.alloc(words * 4));
             const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
@@ -940,7 +940,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const bool lists = iisph_lists();
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
-        if (lists) launch_density_wide<R, KSET, HAS_B>(stream, P, G, hb, posB.as<T4>(), dens.as<R>(), N);
+        // (wall workgroups for the scan only: the list kernels of the chain treat every particle alike)
+        const bool walls = HAS_B && lists && wallListed;
+        if (walls) NRSCHK(build_wall_list(N));
+        const WallList wv = wall_view();
+        if (lists) launch_density_wide<R, KSET, HAS_B>(stream, P, G, hb, posB.as<T4>(), dens.as<R>(), N, walls ? &wv : (const WallList *)nullptr);
         else hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), (R *)nullptr, N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_DENSITY) return NRS_OK;

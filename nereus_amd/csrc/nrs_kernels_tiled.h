@@ -755,7 +755,10 @@ __global__ __launch_bounds__(BLOCK, (((DEFER || (NRS_COMPACT_SCAN && !HAS_B && S
                                                          R *__restrict__ dens, R *__restrict__ pres, HitBuffer hb,
                                                          uint32_t n, WallList wl, uint32_t wallBlocks)
 {
-    __shared__ uint32_t lst[SCAN_CAP + 3][BLOCK]; // (rows SCAN_CAP .. SCAN_CAP + 2: spill rows of the branch-free append, Sweep::scan_compact)
+    // (rows SCAN_CAP .. SCAN_CAP + 2: spill rows of the branch-free append, Sweep::scan_compact; kernels without the quantised scan
+    // keep the 20 KiB that let 8 workgroups share a CU)
+    constexpr int LIST_ROWS = (NRS_COMPACT_SCAN && SHARE && (DEFER || !HAS_B)) ? SCAN_CAP + 3 : HIT_CAP;
+    __shared__ uint32_t lst[LIST_ROWS][BLOCK];
     uint32_t block = blockIdx.x, blocks = gridDim.x;
     if (DEFER) {
         if (block < wallBlocks) {
@@ -1010,11 +1013,18 @@ static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, 
 }
 template <typename R, int KSET, bool HAS_B>
 static inline void launch_density_wide(hipStream_t stream, const Params<R> &P, const GridView<R> &G, const HitBuffer &hb,
-                                       const typename Vec4T<R>::type *sPos, R *dens, uint32_t n)
+                                       const typename Vec4T<R>::type *sPos, R *dens, uint32_t n, const WallList *wall = nullptr)
 {
     const CutThresholds thr = make_thresholds<R>(P);
     const WallList none = {nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true, true>), dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, P, G, thr,
+    const uint32_t g = (n + BLOCK - 1) / BLOCK;
+    if (HAS_B && wall) { // wall workgroups (boundary code, exact positions) + interior workgroups (quantised scan), see k_density_tiled
+        const uint32_t wb = wall_blocks(g);
+        hipLaunchKernelGGL((k_density_tiled<R, KSET, false, true, true, true>), dim3(g + wb), dim3(BLOCK), 0, stream, P, G, thr, sPos, dens,
+                           (R *)nullptr, hb, n, *wall, wb);
+        return;
+    }
+    hipLaunchKernelGGL((k_density_tiled<R, KSET, HAS_B, true, true>), dim3(g), dim3(BLOCK), 0, stream, P, G, thr,
                        sPos, dens, (R *)nullptr, hb, n, none, 0u);
 }
 // `lists`: hit lists published by launch_density_tiled of the same step (then no scan), or nullptr
