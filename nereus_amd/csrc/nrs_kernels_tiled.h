@@ -189,6 +189,9 @@ template <typename R> struct Sweep {
                 bmask = 0u;
 #endif
                 anyB = anyB || bmask != 0u;
+                // BFILT 2 (Monaghan, shared lists): EVERY boundary particle of the 27 cells contributes to the force loop, so a list of
+                // them is the boundary cell table itself — density_from_hits / forces_from_hits walk it (BOUNDARY_BY_CELL)
+                if (BFILT == 2) bmask = 0u;
                 // boundary cells of this plane, visited in ascending cell number by the lanes that have any
                 // (a wave-cooperative sweep — one wall lane at a time, 64 candidates per round, hits ranked with a ballot — was
                 // measured SLOWER, 0.756 vs 0.711 ms at 10 M particles: the two wall lanes of a wave already share one instruction
@@ -397,13 +400,51 @@ struct HitMerge {
 // ---- phase 2 of the density (computeDensityPressure, sph_kernel_impl.cuh:365-433): hits → rho -----------
 // STRICT: the list is the wide IISPH one (self included, fluid kept up to r2LeH2): apply the density loop's own
 // `j != self` and `length < h` tests (sph_kernel_impl.cuh:305-309).
-template <typename R, int KSET, bool HAS_B, bool STRICT = false>
+template <typename R, int KSET, bool HAS_B, bool STRICT = false, bool BOUNDARY_BY_CELL = false>
 NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const typename Vec4T<R>::type *__restrict__ sPos,
                             V3<R> p, const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu)
 {
     const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass, rd = P.restDensity;
     R d = (R)0.0;
     d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
+    if (BOUNDARY_BY_CELL) {
+        // no boundary list (see Sweep::scan, BFILT 2): cell by cell in the reference's order, the fluid hits of the cell from the
+        // list, then the cell's boundary particles straight from the boundary cell table; one partial sum per group, as below
+        const I3 gp = calcGridPos<R>(P, p);
+        int k = 0;
+        uint32_t head = hc.nf > 0 ? lbase[0] : 0xffffffffu;
+        uint32_t c = 0;
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++, c++) {
+                    if ((head >> HIT_TAG_SHIFT) == c) {
+                        R part = (R)0.0;
+                        do {
+                            const uint32_t j = head & HIT_INDEX;
+                            const V3<R> r = p - xyz<R>(sPos[j]);
+                            if (!STRICT || ((j != self) && (length(r) < ir))) part += (pm * W_dens<R, KSET>(r, ir, kp));
+                            ++k;
+                            head = k < hc.nf ? lbase[(uint32_t)k * lstride] : 0xffffffffu;
+                        } while ((head >> HIT_TAG_SHIFT) == c);
+                        d += part;
+                    }
+                    if (hc.anyB) {
+                        const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                        const uint32_t sB = G.bCellStart[h];
+                        if (sB != CELL_EMPTY) {
+                            const uint32_t eB = G.bCellEnd[h];
+                            R part = (R)0.0;
+                            for (uint32_t j = sB; j < eB; ++j) {
+                                const typename Vec4T<R>::type b = G.sB[j];
+                                const V3<R> r = p - xyz<R>(b);
+                                if (length(r) < ir) part += ((rd * b.w) * W_dens<R, KSET>(r, ir, kp));
+                            }
+                            d += part;
+                        }
+                    }
+                }
+        return d;
+    }
     R part = (R)0.0; // the reference adds one partial sum per (cell, fluid|boundary)
     uint32_t prevKey = 0xffffffffu;
     HitMerge it(lbase, lstride, hc);
@@ -514,7 +555,7 @@ NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3
 }
 
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
-template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false, bool PAIRS = false>
+template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false, bool PAIRS = false, bool BOUNDARY_BY_CELL = false>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sPos,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
@@ -535,6 +576,74 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
     else kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
     const R epsilon = (R)0.01;
     const R beta = P.beta, rd = P.restDensity;
+    auto boundaryHit = [&](const BoundaryTerms<R, KSET> &T) {
+        A.fbound = A.fbound + T.bound;
+        A.fpres = A.fpres + T.pres;
+        A.fvisc = A.fvisc - T.visc;
+    };
+    auto fluidHit = [&](uint32_t j) {
+        const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
+        if (STRICT && ((j == self) || !(length(p1p2) < ir))) return; // the loop's own tests (:494,:505)
+        R prq2, mrho2; // pres2 / (dens2 * dens2), m2 / dens2
+        if (PAIRS) {
+            const PrePair<R> q = pairs[j];
+            prq2 = q.prq; mrho2 = q.mrho;
+        } else {
+            const R dens2 = sDens[j];
+            const R pres2 = sPres[j];
+            const R d2sq = dens2 * dens2;
+            prq2 = pres2 / d2sq; mrho2 = m2 / dens2;
+        }
+        const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
+        V3<R> kpressure_grad, kvisco_grad;
+        R kernel;
+        if (KSET == KS_MONAGHAN) {
+            kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
+            kvisco_grad = kpressure_grad;
+            kernel = Wmonaghan<R>(p1p2, ir);
+        } else {
+            kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
+            kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
+            kernel = Wdefault<R>(p1p2, ir, kp);
+        }
+        A.fpres = A.fpres + (m2 * (pres / d1sq + prq2) * kpressure_grad);
+        const R a = dot(p1p2, kvisco_grad);
+        const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
+        A.fvisc = A.fvisc + (mrho2 * v1v2 * (a / b));
+        if (SURF) {
+            V3<R> ai = mk3<R>(0, 0, 0);
+            const R r2 = dot(p1p2, p1p2);
+            if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
+            else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+            A.fsurf = A.fsurf + ai;
+        }
+    };
+    if (BOUNDARY_BY_CELL) {
+        // no boundary list (Sweep::scan, BFILT 2): the fluid hits of each cell from the list, then ALL boundary particles of the cell
+        // from the boundary cell table, in the reference's cell order (computeForces walks z, y, x; sph_kernel_impl.cuh:642-660)
+        const I3 gp = calcGridPos<R>(P, pos1);
+        int k = 0;
+        uint32_t head = hc.nf > 0 ? lbase[0] : 0xffffffffu;
+        uint32_t c = 0;
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++, c++) {
+                    while ((head >> HIT_TAG_SHIFT) == c) {
+                        fluidHit(head & HIT_INDEX);
+                        ++k;
+                        head = k < hc.nf ? lbase[(uint32_t)k * lstride] : 0xffffffffu;
+                    }
+                    if (hc.anyB) {
+                        const uint32_t h = calcGridHash<R>(P, gp.x + x, gp.y + y, gp.z + z);
+                        const uint32_t sB = G.bCellStart[h];
+                        if (sB != CELL_EMPTY) {
+                            const uint32_t eB = G.bCellEnd[h];
+                            for (uint32_t j = sB; j < eB; ++j) boundaryHit(boundary_terms<R, KSET>(P, pos1, vel1, dens, pres, G.sB[j]));
+                        }
+                    }
+                }
+        return A;
+    }
     HitMerge it(lbase, lstride, hc);
     uint32_t j, key;
     bool isB;
@@ -547,45 +656,9 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
             } else {
                 T = boundary_terms<R, KSET>(P, pos1, vel1, dens, pres, G.sB[j]);
             }
-            A.fbound = A.fbound + T.bound;
-            A.fpres = A.fpres + T.pres;
-            A.fvisc = A.fvisc - T.visc;
+            boundaryHit(T);
         } else {
-            const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
-            if (STRICT && ((j == self) || !(length(p1p2) < ir))) continue; // the loop's own tests (:494,:505)
-            R prq2, mrho2; // pres2 / (dens2 * dens2), m2 / dens2
-            if (PAIRS) {
-                const PrePair<R> q = pairs[j];
-                prq2 = q.prq; mrho2 = q.mrho;
-            } else {
-                const R dens2 = sDens[j];
-                const R pres2 = sPres[j];
-                const R d2sq = dens2 * dens2;
-                prq2 = pres2 / d2sq; mrho2 = m2 / dens2;
-            }
-            const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
-            V3<R> kpressure_grad, kvisco_grad;
-            R kernel;
-            if (KSET == KS_MONAGHAN) {
-                kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
-                kvisco_grad = kpressure_grad;
-                kernel = Wmonaghan<R>(p1p2, ir);
-            } else {
-                kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
-                kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
-                kernel = Wdefault<R>(p1p2, ir, kp);
-            }
-            A.fpres = A.fpres + (m2 * (pres / d1sq + prq2) * kpressure_grad);
-            const R a = dot(p1p2, kvisco_grad);
-            const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
-            A.fvisc = A.fvisc + (mrho2 * v1v2 * (a / b));
-            if (SURF) {
-                V3<R> ai = mk3<R>(0, 0, 0);
-                const R r2 = dot(p1p2, p1p2);
-                if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
-                else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
-                A.fsurf = A.fsurf + ai;
-            }
+            fluidHit(j);
         }
     }
     return A;
@@ -722,7 +795,7 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
     } else {
         hc = Sweep<R>::template scan<HAS_B, BF, BLOCK, WIDE>(P, G, thr, sPos, WIDE ? 0xffffffffu : i, p, lst);
         if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow: reference-order path
-        else d = density_from_hits<R, KSET, HAS_B, WIDE>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
+        else d = density_from_hits<R, KSET, HAS_B, WIDE, (HAS_B && BF == 2)>(P, G, sPos, p, &lst[0][tid], BLOCK, hc, i);
     }
     dens[i] = d;
     if (pres) {
@@ -876,7 +949,7 @@ __global__ __launch_bounds__(BLOCK) void k_forces_tiled(Params<R> P, GridView<R>
         const HitCounts hc = Sweep<R>::template scan<HAS_B, BF, BLOCK>(P, G, thr, sPos, i, pos1, lst);
         ForceAcc<R> A;
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
-        else A = forces_from_hits<R, KSET, SURF, HAS_B>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, &lst[0][tid], BLOCK, hc);
+        else A = forces_from_hits<R, KSET, SURF, HAS_B, false, false, (HAS_B && BF == 2)>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, &lst[0][tid], BLOCK, hc);
         f = sesph_total_force<R>(P, A, dens);
     }
     forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
@@ -898,7 +971,7 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
         ForceAcc<R> A;
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
         else // (the context hands out lists only together with the pairs array of the same density launch)
-            A = forces_from_hits<R, KSET, SURF, HAS_B, false, NRS_FORCE_PAIRS != 0>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride,
+            A = forces_from_hits<R, KSET, SURF, HAS_B, false, NRS_FORCE_PAIRS != 0, (HAS_B && KSET == KS_MONAGHAN)>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride,
                                                                                      hc, 0xffffffffu, nullptr, reinterpret_cast<const PrePair<R> *>(hb.pairs));
         f = sesph_total_force<R>(P, A, dens);
     }
