@@ -363,7 +363,13 @@ def bench_main(args, lattice, rank, world, local_rank):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # NEREUS_BENCH_REBALANCE=K: count-balanced re-cut every K steps inside the timed region (off by default: in a 100-step window
+    # that starts from the resting column the cuts have nothing to follow yet, and the re-cut costs a histogram + an all-reduce)
+    rebalance_every = int(os.environ.get("NEREUS_BENCH_REBALANCE", "0"))
+    grid_x = int(p["gridSize"][0][0])
+    for it in range(args.steps):
+        if rebalance_every and it and it % rebalance_every == 0:
+            drv.rebalance(grid_x, msg_cap // 4)
         drv.exchange()
         eng.step(1)
     eng.synchronize()
