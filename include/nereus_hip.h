@@ -74,9 +74,9 @@ enum {
     NRS_FLAG_FULL_SORT = 1u << 4,       /* sort all (hash, index) pairs from scratch every step, as the reference does
                                            (sph_cuda.cu:310-313); default: only the particles that changed cell are
                                            sorted and merged into the still-sorted rest (same result, element for element) */
-    NRS_FLAG_FAST_ARITH = 1u << 5,      /* tolerance mode (fp32, Muller kernels, SESPH): reciprocals instead of IEEE divisions,
-                                           v_rsq instead of correctly rounded square roots, float powers, fused multiply-adds,
-                                           density summed inside the neighbour scan.  Hash / index / cell tables are unaffected
+    NRS_FLAG_FAST_ARITH = 1u << 5,      /* tolerance mode (fp32, Muller kernels, SESPH) of the FORCE walk: reciprocals instead of
+                                           IEEE divisions, v_rsq instead of correctly rounded square roots, float powers, fused
+                                           multiply-adds (the density stays exact).  Hash / index / cell tables are unaffected
                                            (calcGridPos keeps its true division); densities, forces and the integrated state agree
                                            with the default reference-order IEEE arithmetic to ~1e-6 relative per step.  The
                                            reference itself is built with --use_fast_math (CMakeLists.txt:85).  Ignored (exact

@@ -149,19 +149,19 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf fastQ;             // NRS_FLAG_FAST_ARITH: (p/rho^2, 1/rho) per sorted slot, density kernel -> force kernel
     // LDS-staged density scan (nrs_kernels_staged.h): fp32 SESPH on power-of-two grids.  Measured at 10 M particles it is
     // SLOWER than the global-memory scan in the exact arithmetic (0.84 vs 0.71 ms: the kernel is bound by vector-instruction
-    // issue, not by the latency the staging removes) and on par with it in the fast arithmetic, whose in-scan
-    // density sum it carries: it runs for NRS_FLAG_FAST_ARITH contexts only (NEREUS_STAGED=1 forces it, =0 forbids it).
+    // issue, not by the latency the staging removes), and since the quantised scan (0.52 ms) also slower than the
+    // exact path in its own fast arithmetic (0.70-0.88 ms): it runs only when NEREUS_STAGED=1 asks for it.
     bool stagedScan() const
     {
         static const int mode = getenv("NEREUS_STAGED") ? atoi(getenv("NEREUS_STAGED")) : -1;
         if (mode == 0 || !std::is_same<R, float>::value || iisph() || refOrder() || P.numCells > (1u << 30)) return false;
-        return mode == 1 || ((cfg.flags & NRS_FLAG_FAST_ARITH) && KSET == KS_MULLER && lists_ok());
+        return mode == 1 && KSET == KS_MULLER && lists_ok();
     }
-    // fast arithmetic (reciprocals, rsq, fused multiply-adds, density summed in the scan): fp32 Muller SESPH on the
-    // production kernels with shared lists; everything else keeps the reference-order IEEE arithmetic
+    // fast arithmetic (reciprocals, rsq, fused multiply-adds) in the FORCE walk: fp32 Muller SESPH on the production kernels with
+    // shared lists; the density kernel (exact) leaves the (p/rho^2, 1/rho) pairs it needs; everything else keeps IEEE arithmetic
     bool fastArith() const
     {
-        return (cfg.flags & NRS_FLAG_FAST_ARITH) && std::is_same<R, float>::value && KSET == KS_MULLER && stagedScan() && lists_ok();
+        return (cfg.flags & NRS_FLAG_FAST_ARITH) && std::is_same<R, float>::value && KSET == KS_MULLER && !iisph() && !refOrder() && lists_ok();
     }
     // coherent re-sort (nrs_kernels_resort.h)
     DevBuf rsMovers, rsMoversAlt, rsStayers, rsMerged, rsTileMovers, rsTileOffset, rsGroupTotal, rsGroupPrefix, rsScalars, rsPrevPacked;
@@ -794,6 +794,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         // the density kernel's hit lists are handed to the force kernel when both run in this call
         HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         if (NRS_FORCE_PAIRS) hb.pairs = pairBuf.p;
+        if constexpr (std::is_same<R, float>::value) { if (fastArith() && fastQ.p && !stagedScan()) hb.fast = fastQ.as<FastPair>(); }
         const bool share = !refOrder() && lists_ok() && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         const bool fast = fastArith() && share && fastQ.p;

@@ -680,7 +680,10 @@ NRS_DEV uint32_t xcd_tile(uint32_t b, uint32_t nb)
 // pairs (SESPH): per sorted slot (p / rho^2, m / rho), formed ONCE by the density kernel with the operands and the divisions the
 // force loop would use for that neighbour (computeCellForces, sph_kernel_impl.cuh:531,541) — two IEEE divisions less per hit there,
 // one 8-byte gather instead of two 4-byte ones; bit-identical by construction.  null = the force loop divides itself.
-struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; void *pairs = nullptr; };
+// fast (NRS_FLAG_FAST_ARITH): per sorted slot (p * (1/rho)^2, 1/rho) with a hardware reciprocal, for the tolerance-mode force kernel
+// (nrs_kernels_staged.h, k_forces_fast); the density itself stays exact.
+struct FastPair { float pr, invRho; };
+struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; void *pairs = nullptr; FastPair *fast = nullptr; };
 NRS_DEV uint32_t pack_counts(HitCounts hc)
 {
     return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u) | (hc.anyB ? 1u << 17 : 0u);
@@ -806,6 +809,12 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
             q.prq = pr / (d * d);
             q.mrho = P.particleMass / d;
             reinterpret_cast<PrePair<R> *>(hb.pairs)[i] = q;
+        }
+        if (SHARE && hb.fast) {
+            const float inv = __builtin_amdgcn_rcpf((float)d);
+            FastPair z;
+            z.pr = (float)pr * inv * inv; z.invRho = inv;
+            hb.fast[i] = z;
         }
     }
     if (SHARE) {
