@@ -1,7 +1,7 @@
 #!/bin/bash
 # fixed-state timing of the density / force stages for library variants; stops at the first failing step
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02v; mkdir -p $O; : > $O/log.txt
+O=gpurun_out/ab; mkdir -p $O; : > $O/log.txt
 if [ "$1" = "--parity" ]; then shift
   timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -m gpu -q -x > $O/pytest.log 2>&1 || { tail -15 $O/pytest.log; exit 1; }
   tail -2 $O/pytest.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # occupancy sensitivity of the density kernel (dynamic LDS padding lowers the workgroups per CU): fixed-state timing
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02w; mkdir -p $O; : > $O/log.txt
+O=gpurun_out/occ; mkdir -p $O; : > $O/log.txt
 export NEREUS_HIP_LIB=$PWD/tools/_bin/libnereus_hip_pre2.so
 timeout -k 10 300 python tools/density_ablate2.py save 760 /tmp/dev760.npz >> $O/log.txt 2>&1 || { tail -5 $O/log.txt; exit 1; }
 for pad in 0 5000 13000 25000; do
