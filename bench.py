@@ -250,6 +250,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("NEREUS_BENCH_BACKEND") == "gloo" and local_rank >= torch.cuda.device_count():
+        local_rank %= torch.cuda.device_count()  # rehearsal of the N-rank path on a box with fewer GPUs (host-staged exchange only)
     torch.cuda.set_device(local_rank)
 
     from nereus_amd import capi, scene
