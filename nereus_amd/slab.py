@@ -339,13 +339,17 @@ def bench_main(args, lattice, rank, world, local_rank):
     else:
         dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    params = default_params(0)
+    iisph = getattr(args, "solver", "sesph") == "iisph"
+    halo = IISPH_HALO_CELLS if iisph else HALO_CELLS
+    params = default_params(1 if iisph else 0)
     t_gen = time.perf_counter()
     p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
     t_gen = time.perf_counter() - t_gen
     nx, ny, nz = lattice
     msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos))
-    eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank)
+    if iisph:  # wider halo (8 cells instead of 2): four times the halo particles per message
+        msg_cap, cap = 4 * msg_cap, cap + 6 * msg_cap
+    eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank, halo=halo, iisph=iisph)
     eng.load(pos, vel, bi, vbi)
     drv = SlabDriver(eng, rank, world, stage_through_host=(backend != "nccl"))
     n_global = info["particles"]
@@ -371,7 +375,10 @@ def bench_main(args, lattice, rank, world, local_rank):
         if rebalance_every and it and it % rebalance_every == 0:
             drv.rebalance(grid_x, msg_cap // 4)
         drv.exchange()
-        eng.step(1)
+        if iisph:
+            drv.iisph_step()
+        else:
+            eng.step(1)
     eng.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
@@ -396,13 +403,20 @@ def bench_main(args, lattice, rank, world, local_rank):
     num_cells = int(p["numCells"][0])
     value = n_global * args.steps / dt
     bpp, passes = sesph_bytes_per_particle_step(num_cells)
+    if iisph:
+        from bench import iisph_stage_bytes
+
+        ib = iisph_stage_bytes(4)
+        iters = int(getattr(drv, "last_iterations", 2))
+        STAGE_BYTES_F32 = dict(STAGE_BYTES_F32, **{k: v for k, v in ib.items()})
+        bpp = bpp - STAGE_BYTES_F32.get("density", 0) - FUSED_FORCES_BYTES_F32 + sum(v * (iters if k == "i_solve" else 1) for k, v in ib.items())
     n_local = eng.n_local
     fused = dominant == "forces" and "integrate" not in warm
     dom_bytes = (FUSED_FORCES_BYTES_F32 if fused else STAGE_BYTES_F32.get(dominant, 0)) * n_local
     dom_avg_ms = dom_ms / max(1, dom_launches)
     achieved = (dom_bytes / (dom_avg_ms * 1e-3)) / 1e9 if dom_avg_ms > 0 else 0.0
     out = {
-        "metric": "particle-steps/sec, SESPH dam-break",
+        "metric": "particle-steps/sec, %s dam-break" % ("IISPH" if iisph else "SESPH"),
         "value": value,
         "unit": "particle-steps/s",
         "n_gpus": world,
@@ -416,9 +430,9 @@ def bench_main(args, lattice, rank, world, local_rank):
         "data": "synthetic",
         "backend": "rccl" if backend == "nccl" else "gloo+host-staging",
         "config": {
-            "workload": "SESPH dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
+            "workload": ("IISPH" if iisph else "SESPH") + " dam-break %dx%dx%d = %d particles (%d per GPU), fp32, Muller kernels, global grid %dx%dx%d, "
                         "x-slabs with a %d-cell halo exchanged per step by %s"
-                        % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (HALO_CELLS,) +
+                        % ((nx * world, ny, nz, n_global, nx * ny * nz) + tuple(int(v) for v in p["gridSize"][0]) + (halo,) +
                            ("RCCL send/recv" if backend == "nccl" else "gloo send/recv staged through host memory (NEREUS_BENCH_BACKEND=gloo)",)),
             "particles": n_global,
             "num_cells": num_cells,
