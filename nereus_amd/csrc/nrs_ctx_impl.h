@@ -123,7 +123,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     DevBuf errWord; // set by the device-side consistency guard of the scans (GridView::err)
     DevBuf hitBuf, hitCounts; // hit lists shared by the density and force kernels of a step
     // wall-particle deferral (nrs_kernels_tiled.h): static near-boundary bit per cell, this step's wall list
-    DevBuf nearBits, wallList, wallTile, wallTileOffset, wallGroupTotal, wallGroupPrefix, wallScalars;
+    DevBuf nearBits, wallList, wallTile, wallTileOffset, wallGroupTotal, wallGroupPrefix, wallScalars, wallMask;
     bool nearBitsValid = false;
     bool wallListed = false; // this step's gathers run with wall workgroups
     bool deferWalls() const
@@ -131,7 +131,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         static const bool allow = !(getenv("NEREUS_WALL_PASS") && atoi(getenv("NEREUS_WALL_PASS")) == 0);
         return allow && nearBitsValid && nb != 0 && (!iisph() || iisph_lists()) && !refOrder() && lists_ok();
     }
-    WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1}; }
+    WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1, wallMask.as<unsigned long long>()}; }
     // this step's wall list: tile counts (reorder kernel) -> two-level scan (the re-sort's scan kernel) -> stable compaction
     int build_wall_list(uint32_t N)
     {
@@ -278,7 +278,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &qpos, &pairBuf, &fastQ, &nearBits, &wallList, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &qpos, &pairBuf, &fastQ, &nearBits, &wallList, &wallMask, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -502,6 +502,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             const size_t nTiles = (cap + BLOCK - 1) / BLOCK, nGroups = (nTiles + RESORT_GROUP - 1) / RESORT_GROUP;
             NRSCHK(wallList.alloc((size_t)cap * 4));
             NRSCHK(wallTile.alloc(nTiles * 4)); NRSCHK(wallTileOffset.alloc(nTiles * 4));
+            NRSCHK(wallMask.alloc(nTiles * 4 * 8));
             NRSCHK(wallGroupTotal.alloc(nGroups * 4)); NRSCHK(wallGroupPrefix.alloc(nGroups * 4)); NRSCHK(wallScalars.alloc(16));
             HIPCHK(hipMemsetAsync(wallScalars.p, 0, 16, stream));
             HIPCHK(hipMemsetAsync(nearBits.p, 0, words * 4, stream));
@@ -710,13 +711,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             hipLaunchKernelGGL((k_reorder_merged<R>), g, b, 0, stream, merged, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                                cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
-                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), qc,
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), wallMask.as<unsigned long long>(), qc,
                                lists_ok() ? qpos.as<qword_t>() : (qword_t *)nullptr);
         else
             hipLaunchKernelGGL((k_reorder<R>), g, b, 0, stream, hashCur, indexCur, posA.as<T4>(), velA.as<T4>(),
                                iisph() ? presA.as<R>() : (const R *)nullptr, posB.as<T4>(), velB.as<T4>(), presB.as<R>(),
                                cellStart.as<uint32_t>(), cellEnd.as<uint32_t>(), iisph() ? inv.as<uint32_t>() : (uint32_t *)nullptr, N,
-                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), qc,
+                               wallListed ? nearBits.as<uint32_t>() : (const uint32_t *)nullptr, wallTile.as<uint32_t>(), wallMask.as<unsigned long long>(), qc,
                                lists_ok() ? qpos.as<qword_t>() : (qword_t *)nullptr);
         if (iisph() && (cfg.flags & NRS_FLAG_IISPH_SELF_BY_SLOT)) // Q5 off: the pressure kernels skip j == own slot
             hipLaunchKernelGGL(k_identity, g, b, 0, stream, inv.as<uint32_t>(), N);

@@ -70,16 +70,21 @@ struct WallList {
     const uint32_t *hash;     // sorted keys of the step (the cell of every slot)
     const uint32_t *list;     // this step's wall slots, ascending
     const uint32_t *count;    // how many
+    const unsigned long long *mask; // bit per sorted slot (one word per wavefront of the reorder kernel): is it a wall slot
 };
 // Wall slots per 256-slot tile, counted by the reorder kernels while they have each slot's key in a register (first step of the
 // wall-list build: counts -> k_resort_scan_tiles -> k_wall_compact).  Called by EVERY thread of the block (it has a barrier);
 // h is ignored when !live.
-NRS_DEV void wall_tile_count(const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ tileCount, uint32_t h, bool live)
+NRS_DEV void wall_tile_count(const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ tileCount, uint32_t h, bool live,
+                             unsigned long long *__restrict__ slotMask)
 {
     __shared__ uint32_t wallWaveCnt[256 / 64];
     const bool take = live && ((nearBits[h >> 5] >> (h & 31u)) & 1u);
     const unsigned long long m = __ballot(take);
-    if ((threadIdx.x & 63u) == 0) wallWaveCnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    if ((threadIdx.x & 63u) == 0) {
+        wallWaveCnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        slotMask[(blockIdx.x * 256u + threadIdx.x) >> 6] = m; // (the wall-list compaction and the interior workgroups read this instead of the keys)
+    }
     __syncthreads();
     if (threadIdx.x == 0) tileCount[blockIdx.x] = wallWaveCnt[0] + wallWaveCnt[1] + wallWaveCnt[2] + wallWaveCnt[3];
 }
@@ -96,10 +101,10 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
                                                    uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
                                                    uint32_t *__restrict__ inv, uint32_t n,
                                                    const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount,
-                                                   QuantCfg qc, qword_t *__restrict__ qpos)
+                                                   unsigned long long *__restrict__ wallMask, QuantCfg qc, qword_t *__restrict__ qpos)
 {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? hash[i] : 0u, i < n);
+    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? hash[i] : 0u, i < n, wallMask);
     if (i >= n) return;
     const uint32_t h = hash[i];
     if (i == 0) {

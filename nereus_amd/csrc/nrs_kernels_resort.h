@@ -173,10 +173,10 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__rest
                                                           uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
                                                           uint32_t *__restrict__ inv, uint32_t n,
                                                           const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ wallTileCount,
-                                                          QuantCfg qc, qword_t *__restrict__ qpos)
+                                                          unsigned long long *__restrict__ wallMask, QuantCfg qc, qword_t *__restrict__ qpos)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? (uint32_t)(merged[i] >> 32) : 0u, i < n);
+    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? (uint32_t)(merged[i] >> 32) : 0u, i < n, wallMask);
     if (i >= n) return;
     const uint64_t e = merged[i];
     const uint32_t h = (uint32_t)(e >> 32), src = (uint32_t)e;

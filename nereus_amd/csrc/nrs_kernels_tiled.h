@@ -759,8 +759,8 @@ static __global__ __launch_bounds__(BLOCK) void k_wall_compact(WallList wl, cons
 {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const bool take = i < n && cell_near_boundary(wl, wl.hash[i]);
-    const unsigned long long m = __ballot(take);
+    const unsigned long long m = wl.mask[i >> 6]; // (written by the reorder kernel; bits of slots >= n are 0)
+    const bool take = ((m >> lane) & 1ull) != 0ull;
     if (lane == 0) waveCnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (!take) return;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(BLOCK, (((DEFER || (NRS_COMPACT_SCAN && !HAS_B && S
     }
     const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;
     if (i >= n) return;
-    if (DEFER && cell_near_boundary(wl, wl.hash[i])) return; // a wall slot
+    if (DEFER && ((wl.mask[i >> 6] >> (i & 63u)) & 1ull)) return; // a wall slot
     const V3<R> p = xyz<R>(sPos[i]);
     if (!slab_active<R>(P, G, p.x)) {
         dens[i] = (R)0;
@@ -1077,7 +1077,7 @@ static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, 
     const CutThresholds thr = make_thresholds<R>(P);
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     HitBuffer hb = {nullptr, nullptr, 0};
-    const WallList none = {nullptr, nullptr, nullptr, nullptr};
+    const WallList none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // occupancy experiment: extra dynamic LDS per workgroup lowers the workgroups per CU
     static const unsigned pad = getenv("NEREUS_DBG_LDS_PAD") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD")) : 0u;
     if (share) {
@@ -1098,7 +1098,7 @@ static inline void launch_density_wide(hipStream_t stream, const Params<R> &P, c
                                        const typename Vec4T<R>::type *sPos, R *dens, uint32_t n, const WallList *wall = nullptr)
 {
     const CutThresholds thr = make_thresholds<R>(P);
-    const WallList none = {nullptr, nullptr, nullptr, nullptr};
+    const WallList none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const uint32_t g = (n + BLOCK - 1) / BLOCK;
     if (HAS_B && wall) { // wall workgroups (boundary code, exact positions) + interior workgroups (quantised scan), see k_density_tiled
         const uint32_t wb = wall_blocks(g);
@@ -1129,7 +1129,7 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     static const unsigned padF = getenv("NEREUS_DBG_LDS_PAD_F") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD_F")) : 0u; // occupancy experiment
-    const WallList none = {nullptr, nullptr, nullptr, nullptr};
+    const WallList none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (lists && HAS_B && wall) { // wall workgroups + interior workgroups without the boundary code (see k_density_tiled)
         const uint32_t wb = wall_blocks(g.x);
         const dim3 gd(g.x + wb);
