@@ -387,6 +387,10 @@ def main():
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes,
+            # measured separately (not in this run): the gather kernels are bound by vector-instruction issue, not by bytes
+            "limiter_note": ("gather kernels: rocprofv3 VALUBusy 0.85-0.90, TA busy 0.45-0.60 on a 2.1 M-particle scene "
+                             "(tools/busy_counters.sh, profiles/README.md); the HBM fraction on algorithmic bytes understates "
+                             "how close they run to their limit") if dominant in ("density", "forces") else None,
             "whole_step": {
                 "bytes_per_particle_step": bpp,
                 "radix_passes": passes,
