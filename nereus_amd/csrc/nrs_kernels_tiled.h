@@ -11,9 +11,13 @@
 //           organised for memory-level parallelism (measured: the plain cell walk is latency-bound with one
 //           dependent load in flight per thread): 27 table entries per z-plane requested at once, candidate
 //           positions fetched SCAN_BATCH (4) at a time.  Hits are appended to a per-thread list kept in LDS
-//           (lst[k][tid], k-major: conflict-free).  Measured on the final kernel: its time grows like 1 / resident
-//           waves (memory-latency-bound), and every attempt to trade registers for more loads in flight lost
-//           (negative results).
+//           (lst[k][tid], k-major: conflict-free).  This exact-position form (Sweep::scan) serves the wall workgroups, the
+//           kernels without shared lists and contexts whose geometry rules the quantised form out.
+//           Round 2: the interior workgroups scan 4-BYTE QUANTISED candidates instead (Sweep::scan_compact: position modulo
+//           four cells, 10 bits per axis, written by the reorder kernels; integer superset test, branch-free append), and
+//           the process phase applies the exact float cut-off to the exact position it gathers anyway — same lists, same
+//           sums.  Measured: these kernels are bound by vector-instruction issue (VALUBusy 85-90 %), with a latency term
+//           that six waves per SIMD do not hide completely.
 //   process the compacted hits (nearly equal counts across lanes → dense wavefronts) get the expensive
 //           kernel evaluation, in the same order the reference visits them.
 //
@@ -26,7 +30,7 @@
 // The density kernel publishes its lists to global memory (k-major, hits[k][i]) and the force kernel of the same step
 // walks them (k_forces_lists: no second scan, no LDS), fetching the next list head one hit ahead.
 //
-// No MFMA: this is a bandwidth/latency-bound gather, not a dense contraction.
+// No MFMA: this is an issue/latency-bound gather with ~2 kflop per particle-step, not a dense contraction.
 #pragma once
 #include "nrs_kernels_ref.h"
 #include "nrs_kernels_slab.h"
