@@ -75,11 +75,12 @@ struct WallList {
 // Wall slots per 256-slot tile, counted by the reorder kernels while they have each slot's key in a register (first step of the
 // wall-list build: counts -> k_resort_scan_tiles -> k_wall_compact).  Called by EVERY thread of the block (it has a barrier);
 // h is ignored when !live.
+// forceWall: the slot goes to the wall workgroups whatever its cell (an owner the quantised scan cannot serve, see quant_far).
 NRS_DEV void wall_tile_count(const uint32_t *__restrict__ nearBits, uint32_t *__restrict__ tileCount, uint32_t h, bool live,
-                             unsigned long long *__restrict__ slotMask)
+                             unsigned long long *__restrict__ slotMask, bool forceWall = false)
 {
     __shared__ uint32_t wallWaveCnt[256 / 64];
-    const bool take = live && ((nearBits[h >> 5] >> (h & 31u)) & 1u);
+    const bool take = live && (forceWall || ((nearBits[h >> 5] >> (h & 31u)) & 1u));
     const unsigned long long m = __ballot(take);
     if ((threadIdx.x & 63u) == 0) {
         wallWaveCnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
                                                    unsigned long long *__restrict__ wallMask, QuantCfg qc, qword_t *__restrict__ qpos)
 {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? hash[i] : 0u, i < n, wallMask);
+    uint32_t src = 0u;
+    typename Vec4T<R>::type p4 = mk4<R>((R)0, (R)0, (R)0, (R)0);
+    if (i < n) { src = index[i]; p4 = oldPos[src]; }
+    // owners outside the range of the quantised scan (too far from the grid origin, NaN) are handed to the wall workgroups, whose
+    // scan reads exact positions
+    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? hash[i] : 0u, i < n, wallMask, qpos && quant_far<R>(qc, xyz<R>(p4)));
     if (i >= n) return;
     const uint32_t h = hash[i];
     if (i == 0) {
@@ -114,8 +120,6 @@ __global__ __launch_bounds__(BLOCK) void k_reorder(const uint32_t *__restrict__ 
         if (h != hp) { cellStart[h] = i; cellEnd[hp] = i; }
     }
     if (i == n - 1) cellEnd[h] = n;
-    const uint32_t src = index[i];
-    const typename Vec4T<R>::type p4 = oldPos[src];
     sPos[i] = p4;
     if (qpos) qpos[i] = quantize_pos<R>(qc, xyz<R>(p4));
     sVel[i] = oldVel[src];

@@ -176,10 +176,12 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__rest
                                                           unsigned long long *__restrict__ wallMask, QuantCfg qc, qword_t *__restrict__ qpos)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (nearBits) wall_tile_count(nearBits, wallTileCount, i < n ? (uint32_t)(merged[i] >> 32) : 0u, i < n, wallMask);
-    if (i >= n) return;
-    const uint64_t e = merged[i];
+    const uint64_t e = i < n ? merged[i] : 0ull;
     const uint32_t h = (uint32_t)(e >> 32), src = (uint32_t)e;
+    typename Vec4T<R>::type p4 = mk4<R>((R)0, (R)0, (R)0, (R)0);
+    if (i < n) p4 = oldPos[src];
+    if (nearBits) wall_tile_count(nearBits, wallTileCount, h, i < n, wallMask, qpos && quant_far<R>(qc, xyz<R>(p4))); // (far owners: see k_reorder)
+    if (i >= n) return;
     if (i == 0) {
         cellStart[h] = 0;
     } else {
@@ -189,7 +191,6 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_merged(const uint64_t *__rest
     if (i == n - 1) cellEnd[h] = n;
     hashOut[i] = h;
     indexOut[i] = src;
-    const typename Vec4T<R>::type p4 = oldPos[src];
     sPos[i] = p4;
     if (qpos) qpos[i] = quantize_pos<R>(qc, xyz<R>(p4));
     sVel[i] = oldVel[src];

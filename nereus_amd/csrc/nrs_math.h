@@ -238,6 +238,13 @@ NRS_DEV qword_t pack_quanta(float tx, float ty, float tz)
     return kx | (ky << 11) | (kz << 22);
 }
 #endif
+// an owner too far from the grid origin for the error budget of the quanta, or with a NaN coordinate
+template <typename R> NRS_DEV bool quant_far(const QuantCfg &q, V3<R> p)
+{
+    float tx, ty, tz;
+    quantize_t<R>(q, p, tx, ty, tz);
+    return !((fabsf(tx) < QP_FAR) & (fabsf(ty) < QP_FAR) & (fabsf(tz) < QP_FAR));
+}
 template <typename R> NRS_DEV qword_t quantize_pos(const QuantCfg &q, V3<R> p)
 {
     float tx, ty, tz;

@@ -415,9 +415,16 @@ def test_compact_scan_guards(hip_lib):
     narrow["gridSize"][0] = (2, 64, 64)
     narrow["numCells"][0] = 2 * 64 * 64
     cases.append(("grid two cells wide", narrow, near))
-    for name, p, pos in cases:
+    # with boundary particles the far owners are handed to the wall workgroups (exact-position scan) by the reorder kernel
+    wall = np.ones((300, 4), np.float32)
+    wall[:, :3] = (np.array([0.2, 0.1, -0.3]) + rng.uniform(-2.5 * h, 2.5 * h, (300, 3))).astype(np.float32)
+    wall[:, 2] = np.float32(-0.3 - 2.6 * h)
+    cases.append(("far owners, with walls", base, pos, wall, np.full(300, 2e-5, np.float32)))
+    for case in cases:
+        name, p, pos = case[:3]
+        bi, vbi = (case[3], case[4]) if len(case) > 3 else (None, None)
         vel = np.zeros_like(pos)
-        o, s = make_pair(p, pos, vel)
+        o, s = make_pair(p, pos, vel, bi, vbi)
         o.step(1, stop=STOP_FORCES); s.step_partial(capi.STAGE_FORCES)
         np.testing.assert_array_equal(s.get("hash"), o.get("hash"), err_msg=name)
         np.testing.assert_array_equal(s.get("index"), o.get("index"), err_msg=name)
