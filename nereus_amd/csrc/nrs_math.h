@@ -230,7 +230,7 @@ constexpr float QP_PER_CELL = 256.0f;
 // |k_i - k_j - (t_i - t_j)| < 1 (two floors) + 2 * 0.19 (relative error <= 3 * 2^-24 on |t| < 2^20 + 2^9) per axis, so
 // |dk| <= |dt| + 1.38 * sqrt(3) = |dt| + 2.39; + the float rounding of the exact test itself
 constexpr float QP_MARGIN = 2.5f;
-constexpr float QP_FAR = 1048576.0f; // 2^20 quanta = 4096 cells from the grid origin
+constexpr float QP_FAR = 1048576.0f; // 2^20 quanta = 4096 cells from the grid origin: an owner beyond that (or with a NaN coordinate) is scanned on exact positions (quant_far)
 constexpr float QP_HALF = 511.0f;
 NRS_DEV qword_t pack_quanta(float tx, float ty, float tz)
 {
