@@ -600,6 +600,36 @@ def test_full_size_c2_properties(hip_lib):
     assert rel_err(a["forces"], o.get("forces")) <= TOL_STAGE
 
 
+def test_full_size_north_star_production_equals_reference_order(hip_lib):
+    """The bench workload itself (216^3 = 10,077,696 particles + tank, the north-star size): one force evaluation and three full
+    steps on the production path (quantised scan, wall workgroups, pair gathers, fused force launch, coherent re-sort) against the
+    reference-order kernels with a full sort — every array bit for bit; plus the size-independent properties."""
+    p = Oracle.default_params(SESPH)
+    sc = scene.dam_break("NS", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    n = len(sc["pos"])
+    assert n == 216 ** 3
+    res = []
+    for ref in (False, True):
+        s = capi.Solver(p, n, reference_order=ref, flags=capi.FLAG_FULL_SORT if ref else 0)
+        s.set_particles(sc["pos"], sc["vel"])
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step_partial(capi.STAGE_FORCES)
+        r = dict(hash=s.get("hash"), index=s.get("index"), dens=s.get("dens"), pres=s.get("pres"), forces=s.get("forces"))
+        s.set_particles(sc["pos"], sc["vel"])
+        s.step(3)
+        r["pos"], r["vel"] = s.download()
+        if not ref:
+            assert s.resort_stats()[0] >= 2     # the merge path ran
+        res.append(r)
+        s.close()
+    a, b = res
+    assert np.all(np.diff(a["hash"].astype(np.int64)) >= 0)
+    assert np.array_equal(np.sort(a["index"]), np.arange(n, dtype=np.uint32))
+    assert np.isfinite(a["pos"]).all() and np.isfinite(a["vel"]).all() and float(a["dens"].min()) > 0
+    for k in ("hash", "index", "dens", "pres", "forces", "pos", "vel"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_full_size_c2_resort_long_run_bitwise(hip_lib):
     """BASELINE config C2 for 150 steps: the default path (coherent re-sort, fused launches, shared hit lists) and the
     reference-shaped path (full sort every step, separate launches) end in the same bits; the mover fraction grows
