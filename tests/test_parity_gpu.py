@@ -630,6 +630,36 @@ def test_full_size_north_star_production_equals_reference_order(hip_lib):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_full_size_north_star_developed_state_bitwise(hip_lib):
+    """The same scene once the dam has broken (state after 760 steps: ~11 neighbours within h, 11 % movers per step, lists close to
+    their capacity): density, pressure, forces and one full step of the production path against the reference-order kernels, bit
+    for bit, from that state."""
+    p = Oracle.default_params(SESPH)
+    sc = scene.dam_break("NS", h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
+    n = len(sc["pos"])
+    s = capi.Solver(p, n)
+    s.set_particles(sc["pos"], sc["vel"])
+    s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+    s.step(760)
+    pos, vel = s.download()
+    assert np.isfinite(pos).all() and s.get_stat(capi.STAT_HIT_MEAN) > 8.0
+    s.close()
+    res = []
+    for ref in (False, True):
+        s = capi.Solver(p, n, reference_order=ref)
+        s.set_particles(pos, vel)
+        s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
+        s.step_partial(capi.STAGE_FORCES)
+        r = dict(index=s.get("index"), dens=s.get("dens"), pres=s.get("pres"), forces=s.get("forces"))
+        s.set_particles(pos, vel)
+        s.step(1)
+        r["pos"], r["vel"] = s.download()
+        res.append(r)
+        s.close()
+    for k in res[0]:
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+
+
 def test_full_size_c2_resort_long_run_bitwise(hip_lib):
     """BASELINE config C2 for 150 steps: the default path (coherent re-sort, fused launches, shared hit lists) and the
     reference-shaped path (full sort every step, separate launches) end in the same bits; the mover fraction grows
