@@ -17,6 +17,8 @@ def make_scene(seed):
     real = np.float64 if double else np.float32
     h = float(p["interactionRadius"][0])
     n = int(rng.integers(500, 30000))
+    if seed % 11 == 10:  # large enough for the coherent re-sort (merge path) of the production steps
+        n = int(rng.integers(40000, 150000))
     ext = rng.uniform(4, 30, 3) * h * np.array([1.0, rng.uniform(0.3, 1.0), rng.uniform(0.3, 1.0)])
     centre = rng.uniform(-0.5, 0.5, 3)
     pos = np.ones((n, 4), real)
@@ -63,7 +65,7 @@ def one(seed):
         o = [s.get("dens"), s.get("forcesP") if solver == capi.IISPH else s.get("forces")]
         iters.append(s.last_iterations if solver == capi.IISPH else 0)
         s.set_particles(pos, vel)
-        s.step(3)
+        s.step(6 if n >= 40000 else 3)
         o += list(s.download())
         outs.append(o)
         s.close()
