@@ -22,3 +22,14 @@ def test_random_scenes_production_equals_reference_order(hip_lib):
             failures.append(r)
     assert not failures, failures[:3]
     assert diverged < 40
+
+
+@pytest.mark.gpu
+def test_random_slab_runs_equal_single_domain(hip_lib):
+    """A slice of tools/fuzz_slab.py: 2-4 ranks as contexts of this process, random cuts / re-cuts / migrations."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fuzz_slab import STATS, one
+
+    failures = [r for r in (one(seed) for seed in range(7000, 7012)) if r and r != "skip"]
+    assert not failures, failures[:3]
+    assert STATS["migrants"] > 0
