@@ -4,7 +4,7 @@ pre-classified partitions, re-cuts, the per-rank cell-table window) is the produ
 random cuts, random velocities that carry particles across the cuts, random re-cuts between steps; after K steps the union of the
 owned particles is compared (by id) with a single-domain production run of the same scene: ids conserved, positions and velocities
 within 1e-5 (the order of the particles inside a cell — hence the rounding of the sums — depends on the partition).
-usage: python tools/fuzz_slab.py [seeds=50] [first=0] [sesph|iisph]"""
+usage: python tools/fuzz_slab.py [seeds=50] [first=0] [sesph|iisph]      (FUZZ_SLAB_BIG=1: every rank above 32,768 particles)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ import torch
 from nereus_amd import capi, scene, slab
 from nereus_amd.params import default_params, update_grid
 
+BIG = os.environ.get("FUZZ_SLAB_BIG") == "1"
 STATS = {"migrants": 0, "merge_steps": 0, "full_sorts": 0, "particles": 0, "ranks": 0}
 
 def rel(a, b):
@@ -29,6 +30,9 @@ def one(seed, iisph=False):
     nx = int(rng.integers(world * (2 * halo + 6) + 4, world * (2 * halo + 6) + 60))
     if nx * ny * nz < 34000 and rng.random() < 0.7:   # mostly big enough for the in-place partition and the merge path
         ny, nz = max(ny, 24), max(nz, 24)
+    if BIG:   # every rank above the 32,768 particles from which the partition works in place and the steps merge
+        ny, nz = int(rng.integers(34, 52)), int(rng.integers(34, 52))
+        nx = max(nx, int(world * 34000 / (ny * nz)) + world * (2 * halo + 6))
     sc = scene.dam_break((nx, ny, nz), h=h, kpoly=float(p["kpoly"][0]))
     pos = sc["pos"].copy(); n = len(pos)
     vel = np.zeros_like(pos)
