@@ -263,9 +263,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     }
 
     // the tiled kernels assume the power-of-two grids the reference's hash assumes (sph_kernel_impl.cuh:120)
+    bool refOverride = false; // this IISPH step is being repeated with the reference-order kernels (iisph_tail)
     bool refOrder() const
     {
-        return (cfg.flags & NRS_FLAG_REFERENCE_ORDER) != 0 || !is_pow2(P.gridSize[0]) || !is_pow2(P.gridSize[1]) ||
+        return refOverride || (cfg.flags & NRS_FLAG_REFERENCE_ORDER) != 0 || !is_pow2(P.gridSize[0]) || !is_pow2(P.gridSize[1]) ||
                !is_pow2(P.gridSize[2]);
     }
     bool iisph() const { return cfg.solver == NRS_SOLVER_IISPH; }
@@ -342,8 +343,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
                 NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
-        NRSCHK(errWord.alloc(4));
-        HIPCHK(hipMemsetAsync(errWord.p, 0, 4, stream));
+        NRSCHK(errWord.alloc(8)); // [0] run guard of the scans, [1] IISPH: a gathered value went non-finite (IisphArrays::nonFinite)
+        HIPCHK(hipMemsetAsync(errWord.p, 0, 8, stream));
         NRSCHK(redPartial.alloc(sizeof(double) * 1024));
         NRSCHK(redOut.alloc(2 * sizeof(double)));
         // radix sort workspace for the largest problem
@@ -628,6 +629,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         I.velAdv = velAdv.as<T4>(); I.forcesAdv = forcesAdv.as<T4>(); I.forcesP = forcesP.as<T4>();
         I.diiF = diiF.as<T4>(); I.diiB = diiB.as<T4>(); I.sumDij = sumDij.as<T4>(); I.diiSum = diiSum.as<T4>();
         I.inv = inv.as<uint32_t>();
+        I.nonFinite = (iisph_lists() && !slabOn) ? errWord.as<uint32_t>() + 1 : (uint32_t *)nullptr; // (second word of the error buffer)
         return I;
     }
 
@@ -1029,32 +1031,71 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    // The list-driven chain is the reference-order chain only while every value a neighbour gathers is finite (IisphArrays::nonFinite).
+    // A solve that overflows raises the flag; the step is then repeated from the sorted input with the reference-order kernels,
+    // so that even a diverging run produces what the reference's loops produce.  (Not in slab runs, whose loop the host drives.)
     template <bool HAS_B> int iisph_tail(int stop)
     {
+        const bool watch = iisph_lists() && !slabOn;
+        uint32_t *flag = errWord.as<uint32_t>() + 1;
+        if (watch) HIPCHK(hipMemsetAsync(flag, 0, 4, stream));
+        NRSCHK(iisph_tail_once<HAS_B>(stop, watch));
+        if (!watch || !iisphDiverged) return NRS_OK;
+        refOverride = true;
+        ++iisphRestarts;
+        hipLaunchKernelGGL((k_gather_scalar<R>), dim3(nblocks((uint32_t)n)), dim3(BLOCK), 0, stream, presA.as<R>(), indexCur, presB.as<R>(), (uint32_t)n);
+        const int rc = iisph_tail_once<HAS_B>(stop, false);
+        refOverride = false;
+        return rc;
+    }
+    bool iisphDiverged = false;
+    uint64_t iisphRestarts = 0;
+    template <bool HAS_B> int iisph_tail_once(int stop, bool watch)
+    {
         const uint32_t N = (uint32_t)n;
+        iisphDiverged = false;
+        uint32_t hflag = 0u;
+        uint32_t *flag = errWord.as<uint32_t>() + 1;
         NRSCHK(iisph_predict<HAS_B>(stop));
-        if (stop && stop <= NRS_STAGE_I_ADVECTION) return NRS_OK;
+        if (stop && stop <= NRS_STAGE_I_ADVECTION) {
+            if (watch) {
+                HIPCHK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                iisphDiverged = hflag != 0u;
+            }
+            return NRS_OK;
+        }
         // pressureSolve (sph_cuda.cu:702-899): while ((rho_avg - 1000) > 1 || l < 2)
         NRSCHK(ev_begin(NRS_STAGE_I_SOLVE));
         uint32_t l = 0;
         R rho_avg = 0.f;
         const R rd = 1000.f;
         const R max_rho_err = 1.f;
+        bool flagRead = false;
         while (((rho_avg - rd) > max_rho_err) || (l < 2)) {
             NRSCHK(iisph_iteration<HAS_B>());
             l++;
+            flagRead = false;
             if (maxIters && l >= maxIters) break;
             // the loop condition reads rho_avg only once l >= 2 (sph_cuda.cu:736: `|| l < 2`): the average of the first
             // iteration is never looked at, so its reduction and host round trip are skipped
             if (l >= 2) {
                 double acc = 0.0;
+                if (watch) HIPCHK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, stream)); // (rides in the reduction's round trip)
                 NRSCHK(reduce_sum(densCorr.as<R>(), N, &acc));
+                flagRead = true;
+                if (watch && hflag) break;
                 rho_avg = (R)acc;
                 rho_avg /= N;
             }
         }
+        if (watch && !flagRead) {
+            HIPCHK(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
         lastIters = l;
         NRSCHK(ev_end());
+        if (watch && hflag) { iisphDiverged = true; return NRS_OK; } // (the caller repeats the step in reference order)
         if (stop == NRS_STAGE_I_SOLVE) return NRS_OK;
         return iisph_finish<HAS_B>(stop);
     }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
     const V3<R> vel_adv = vel1 + dt * (force_adv / pm);
     I.forcesAdv[i] = mk4<R>(force_adv, (R)0.0);
     I.velAdv[i] = mk4<R>(vel_adv, (R)0.0);
+    watch_finite<R>(I.nonFinite, vel_adv);
     if (hc.over) { // per-cell walk of the reference-order kernel for this particle
         const I3 gp = calcGridPos<R>(P, pos1);
         for (int z = -1; z <= 1; z++)
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
     I.diiF[i] = mk4<R>(df, (R)0.0);
     I.diiB[i] = mk4<R>(db, (R)0.0);
     I.diiSum[i] = mk4<R>(df + db, (R)0.0); // the same sum computePressure forms per neighbour (sph_kernel_impl.cuh:1420)
+    watch_finite<R>(I.nonFinite, df + db);
 }
 
 // ---- computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) --------------------------------------------------
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R>
         dijpj = dijpj + part;
     }
     I.sumDij[i] = mk4<R>(dijpj, (R)0.0);
+    watch_finite<R>(I.nonFinite, dijpj);
 }
 
 // ---- computePressure without boundary particles (sph_kernel_impl.cuh:1330-1492; Q5: skips j == inv[i], keeps self;
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
         p_l = (R)((1.0 - omega) * previous_p_l + (omega / denom) * (b - dt2 * (bsum + fsum)));
     else
         p_l = (R)0.0;
+    watch_finite<R>(I.nonFinite, p_l); // (before the clamp, which would hide a NaN)
     const R p = (R)fmax((double)p_l, 0.0);
     p_l = p;
     rho_corr += aii * previous_p_l;

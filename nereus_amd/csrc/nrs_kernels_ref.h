@@ -411,7 +411,32 @@ template <typename R> struct IisphArrays {
     T4 *diiSum; // diiF + diiB, formed once per step by the list-driven displacement kernel (the pressure kernel's neighbour
                 // term reads only the sum: one 16-byte gather per neighbour and iteration instead of two)
     const uint32_t *inv; // inv[slot] = id of the reference thread that handles the slot
+    // Set by the list-driven kernels when a value that NEIGHBOURS will gather (velAdv, dii, sumDij, P_l) is not finite or so large
+    // that a product or difference of two such values could overflow.  The list walks visit only neighbours inside the kernel
+    // support; the reference's 27-cell walks also multiply the zero gradient of a particle beyond it with expressions of those
+    // values (0 * inf = NaN): identical only while everything stays finite.  The context then repeats the step with the
+    // reference-order kernels (Ctx::iisph_tail).  null: not watched.
+    uint32_t *nonFinite;
 };
+// (1e12: the cube of it is still a finite float — fp64 builds pass scalars through float as well, SURVEY Q11 —; a fluid step has no
+// quantity anywhere near it)
+template <typename R> NRS_DEV R watch_limit() { return (R)1e12; }
+template <typename R> NRS_DEV void watch_finite(uint32_t *flag, V3<R> v)
+{
+    const R lim = watch_limit<R>();
+    if (flag && !((fabs(v.x) < lim) & (fabs(v.y) < lim) & (fabs(v.z) < lim))) *flag = 1u; // (false for NaN too)
+}
+template <typename R> NRS_DEV void watch_finite(uint32_t *flag, R v)
+{
+    if (flag && !(fabs(v) < watch_limit<R>())) *flag = 1u;
+}
+// sPres[i] = pres[index[i]]: the sorted warm-start pressures once more (a step repeated in reference order)
+template <typename R>
+static __global__ __launch_bounds__(BLOCK) void k_gather_scalar(const R *__restrict__ src, const uint32_t *__restrict__ index, R *__restrict__ dst, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[index[i]];
+}
 
 // computeIisphDensity (:770-846) is k_density_ref with pres == nullptr.
 

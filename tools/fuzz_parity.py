@@ -74,7 +74,7 @@ def one(seed):
     # (0 * inf = NaN) — equal for finite operands only.
     # (The solver's max(p, 0) clamp can turn such a NaN into a finite 0, so even finite results may then differ: a solve that ran into
     # its iteration cap is skipped as well.)
-    if not all(np.isfinite(x).all() for x in outs[1]) or (solver == capi.IISPH and iters[1] >= 50):
+    if os.environ.get("FUZZ_SKIP_NONFINITE", "0") == "1" and not all(np.isfinite(x).all() for x in outs[1]):
         return "diverged"
     for k, (a, b) in enumerate(zip(*outs)):
         if not np.array_equal(a, b, equal_nan=True):
@@ -99,7 +99,7 @@ def one_vs_oracle(seed):
         return float(np.abs(x - y).max() / sc_) if sc_ > 0 else float(np.abs(x - y).max())
     fo = o.get("forcesP" if iis else "forces")
     # (IISPH on a random clump may not converge: after dozens of iterations intermediate pressures overflow, see the note in one())
-    if not (np.isfinite(fo).all() and np.isfinite(o.get("dens")).all()) or (iis and o.last_iters >= 50):
+    if not (np.isfinite(fo).all() and np.isfinite(o.get("dens")).all()):
         s.close(); return "diverged"
     msg = None
     if not np.array_equal(s.get("hash"), o.get("hash")) or not np.array_equal(s.get("index"), o.get("index")):
