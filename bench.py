@@ -9,6 +9,12 @@ the timed region starts.  N=1 default workload: the north-star size, a 216^3 = 1
 dam-break (fp32, Muller kernels) in its tank of boundary particles.  For N>1 (launched by torchrun, one rank
 per GPU) the block is N times longer in x and slab-partitioned (weak scaling), see nereus_amd/slab.py.
 
+What is timed is the BROKEN dam, not the resting column (round 3): before the contract's warm-up the run does an
+untimed spin-up (--spin-up, default 3000 steps) under a time step that respects the CFL limit throughout
+(--dt, default 2.5e-4 s: the reference's fixed 1e-3 s passes the limit of this 8.8 m column around step 250 and
+blows up before step 1000).  `config.spin_up_steps`, `config.dt` and `cfl_ok` say so in the
+line; the resting column (steps 20-120 of the same run) is the `resting` sub-record.
+
 Rank 0 prints ONE JSON line: the driver contract plus
   roofline     dominant kernel, ALGORITHMIC bytes per launch / its mean HIP-event duration in the timed
                region, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md)
@@ -28,7 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured-achievable)
-TRAFFIC_PROFILE = "r02b_ns10M_resting_hbm_traffic.json"  # committed rocprofv3 PMC summary the `traffic` field is read from
+TRAFFIC_PROFILE = "r03_ns10M_flowing_hbm_traffic.json"  # committed rocprofv3 PMC summary (of the same window) the `traffic` field is read from
+DEFAULT_SPIN_UP, DEFAULT_DT = 3000, 2.5e-4
 
 
 
@@ -156,57 +163,31 @@ def cpu_baseline(seconds_target=15.0):
     }
 
 
-def developed_record(s, capi, n, skip, steps, steps_before, bpp, real_bytes, torch):
-    """The same step once the dam has broken ("mean of >= 100 steps after warm-up"): `skip` untimed steps
-    after the contract's timed region, then `steps` timed ones with every stage on HIP events.  The resting column of
-    the first steps is the cheapest regime of the whole run (exactly 6 neighbours per particle, no movers)."""
-    s.set_profiling(False)
-    s.step(skip)
+def timed_window(s, steps, torch):
+    """`steps` steps bracketed by synchronisations; returns seconds"""
     s.synchronize()
-    st0, fb0 = s.resort_stats()
-    s.set_profiling(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     s.step(steps)
     s.synchronize()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stages = {k: v[0] / max(1, v[1]) for k, v in s.stage_ms().items()}
-    st1, fb1 = s.resort_stats()
-    rec = {
-        "first_step": steps_before + skip,
-        "steps": steps,
-        "ms_per_step": 1e3 * dt / steps,
-        "value": n * steps / dt,
-        "whole_step_frac": bpp * n * steps / dt / 1e9 / HBM_PEAK_GBS,
-        "stage_ms": stages,
-        "coherent_resort_steps": st1 - st0,
-        "fell_back_to_full_sort": fb1 - fb0,
-    }
-    try:
-        vmax = s.max_velocity()
-        P = s.params
-        h, dtp, cs = float(P["interactionRadius"][0]), float(P["timestep"][0]), float(P["soundSpeed"][0])
-        # the reference steps with a FIXED dt (sph.cpp:60; its CFL rule is compiled out, sph.cpp:217-231): once |v|max passes
-        # 0.4 h / dt - c_s the integration is beyond its stability limit and the column eventually blows up (DESIGN.md §6)
-        rec["vmax"] = vmax
-        rec["cfl_dt_limit"] = 0.4 * h / (cs + vmax)
-        rec["dt"] = dtp
-    except capi.NereusError:
-        pass
+    return time.perf_counter() - t0
+
+
+def flow_state(s, capi, n):
+    """max |v| and the CFL limit of the state (the reference's rule, sph.cpp:217-231: dt <= 0.4 h / (c_s + |v|max)), plus the
+    hit-list diagnostics of the last step"""
+    P = s.params
+    h, dt, cs = float(P["interactionRadius"][0]), float(P["timestep"][0]), float(P["soundSpeed"][0])
+    vmax = s.max_velocity()
+    rec = {"vmax": vmax, "cfl_dt_limit": 0.4 * h / (cs + vmax), "dt": dt, "cells_per_step": vmax * dt / h}
     try:
         rec["mover_fraction_last_step"] = s.get_stat(capi.STAT_MOVERS) / n
         rec["hit_list_overflow_fraction"] = s.get_stat(capi.STAT_HIT_OVERFLOW) / n
         rec["neighbours_mean"] = s.get_stat(capi.STAT_HIT_MEAN)
         rec["neighbours_max"] = s.get_stat(capi.STAT_HIT_MAX)
-        rec["unstaged_fraction"] = s.get_stat(capi.STAT_UNSTAGED) / n
     except capi.NereusError as e:  # (reference-order kernels keep no hit lists)
         rec["stats_unavailable"] = str(e)
-    dom = max(stages, key=stages.get) if stages else None
-    if dom:
-        b = fused_forces_bytes(real_bytes) if (dom == "forces" and "integrate" not in stages) else stage_bytes(real_bytes).get(dom, 0)
-        rec["dominant"] = {"kernel": dom, "kernel_avg_ms": stages[dom],
-                           "frac": b * n / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if stages[dom] > 0 else 0.0}
     return rec
 
 
@@ -228,10 +209,17 @@ def main():
     ap.add_argument("--arith", default="exact", choices=["exact", "fast"],
                     help="exact = every float sum in the reference's order with IEEE arithmetic (bit-identical to the CPU oracle); "
                          "fast = NRS_FLAG_FAST_ARITH (tolerance mode, fp32 Muller SESPH; indices stay bit-exact)")
-    ap.add_argument("--developed", type=int, default=None, metavar="SKIP",
-                    help="N=1 SESPH: after the timed region run SKIP more untimed steps (default 600; 0 = off) and time "
-                         "--developed-steps more: the `developed` sub-record of the JSON line (the dam has broken by then)")
-    ap.add_argument("--developed-steps", type=int, default=100)
+    ap.add_argument("--spin-up", type=int, default=None, metavar="STEPS",
+                    help="untimed steps BEFORE the contract's warm-up that take the scene from the resting column to the broken dam "
+                         "(default %d for SESPH, 0 for IISPH; 0 = time the resting column as rounds 1-2 did)" % DEFAULT_SPIN_UP)
+    ap.add_argument("--dt", type=float, default=None,
+                    help="fixed time step in seconds (default %g for SESPH: CFL-stable through the spin-up and the timed region; "
+                         "IISPH keeps its constructor default).  The reference's own 1e-3 s (sph.cpp:60): --dt 1e-3" % DEFAULT_DT)
+    ap.add_argument("--developed", type=int, default=None, help=argparse.SUPPRESS)  # (rounds 1-2: window behind the timed region; ignored)
+    ap.add_argument("--developed-steps", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--resting-steps", type=int, default=100, help="length of the `resting` sub-record's window (0 = off)")
+    ap.add_argument("--iisph-max-iters", type=int, default=2,
+                    help="N>1 IISPH: solver iterations per step the halo is sized for (halo = 2 * iterations + 4 cells)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-order", action="store_true", help="bench the reference-order kernels instead")
     ap.add_argument("--full-sort", action="store_true", help="sort all pairs from scratch every step (NRS_FLAG_FULL_SORT)")
@@ -304,9 +292,34 @@ def main():
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     P = s.params
     num_cells = int(P["numCells"][0])
+    if args.dt is not None or not iisph:   # (set after the grid exists; a new time step keeps every prepared key, nrs_set_params)
+        P["timestep"][0] = args.dt if args.dt is not None else DEFAULT_DT
+        s.set_params(P)
+    spin_up = args.spin_up if args.spin_up is not None else (0 if iisph else DEFAULT_SPIN_UP)
+    bpp, passes = sesph_bytes_per_particle_step(num_cells, real_bytes)
 
-    # warm-up (untimed), with every stage timed once to find the dominant kernel
-    first = 1 if args.warmup > 1 else 0  # the very first step also pays one-off costs (rocPRIM set-up, the full sort after an upload)
+    # untimed spin-up to the flowing state; on its way the resting column's window (steps 20-120) as a sub-record
+    done = 0
+    resting = None
+    if spin_up > 0:
+        s.step(1)  # (the very first step also pays one-off costs: rocPRIM set-up, the full sort after an upload)
+        done = 1
+        if not iisph and args.resting_steps > 0 and spin_up >= 20 + args.resting_steps:
+            s.step(19)
+            s.set_profiling(True)
+            t_rest = timed_window(s, args.resting_steps, torch)
+            st = {k: v[0] / max(1, v[1]) for k, v in s.stage_ms().items()}
+            s.set_profiling(False)
+            done = 20 + args.resting_steps
+            resting = {"first_step": 20, "steps": args.resting_steps, "ms_per_step": 1e3 * t_rest / args.resting_steps,
+                       "value": n * args.resting_steps / t_rest,
+                       "whole_step_frac": bpp * n * args.resting_steps / t_rest / 1e9 / HBM_PEAK_GBS, "stage_ms": st}
+            resting.update(flow_state(s, capi, n))
+        s.step(spin_up - done)
+        done = spin_up
+
+    # the contract's warm-up (untimed), with every stage timed once to find the dominant kernel
+    first = 1 if (args.warmup > 1 and done == 0) else 0
     s.step(first)
     s.set_profiling(True)
     s.step(args.warmup - first)
@@ -315,15 +328,12 @@ def main():
     dominant = max(warm, key=lambda k: warm[k][0]) if warm else "forces"
     dom_id = {v: k for k, v in capi.STAGE_NAMES.items()}[dominant]
     s.set_profiling([dom_id])
+    before = None if iisph else flow_state(s, capi, n)
 
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s.step(args.steps)
-    s.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed_window(s, args.steps, torch)
     timed = s.stage_ms()
     dom_ms, dom_launches = timed.get(dominant, (0.0, 0))
+    after = None if iisph else flow_state(s, capi, n)
 
     # sanity: the state is finite
     gp, gv = s.download()
@@ -332,7 +342,6 @@ def main():
 
     ms_per_step = 1e3 * dt / args.steps
     value = n * args.steps / dt
-    bpp, passes = sesph_bytes_per_particle_step(num_cells, real_bytes)
     isb = iisph_stage_bytes(real_bytes)
     if iisph:  # 448 + 16 P + 136 L bytes per particle-step (fp32), L = solver iterations of the last step
         sb = stage_bytes(real_bytes)
@@ -369,6 +378,10 @@ def main():
             "boundary_particles": int(len(sc["bi"])),
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
+            "spin_up_steps": spin_up,
+            "first_timed_step": spin_up + args.warmup,
+            "dt": float(s.params["timestep"][0]),
+            "simulated_time_at_window_start_s": (spin_up + args.warmup) * float(s.params["timestep"][0]),
             "kernels": "reference-order" if args.reference_order else "tiled",
             "arith": args.arith if (not double and kset == capi.MULLER and not iisph and not args.reference_order) else "exact",
             "sort": dict(zip(("coherent_resort_steps", "fell_back_to_full_sort"), s.resort_stats())),
@@ -387,10 +400,9 @@ def main():
             "kernel_avg_ms": dom_avg_ms,
             "kernel_launches": dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes,
-            # measured separately (not in this run): the gather kernels are bound by vector-instruction issue, not by bytes
-            "limiter_note": ("gather kernels: rocprofv3 VALUBusy 0.85-0.90, TA busy 0.45-0.60 on a 2.1 M-particle scene "
-                             "(tools/busy_counters.sh, profiles/README.md); the HBM fraction on algorithmic bytes understates "
-                             "how close they run to their limit") if dominant in ("density", "forces") else None,
+            # (not measured in this run) which unit the gather kernels keep busy: see the committed counter summary
+            "limiter_note": ("gather kernels are bound by vector-instruction issue and L1 address traffic, not by HBM bytes: "
+                             "profiles/r03_busy_2M.json") if dominant in ("density", "forces") else None,
             "whole_step": {
                 "bytes_per_particle_step": bpp,
                 "radix_passes": passes,
@@ -406,9 +418,15 @@ def main():
     }
     if iisph:
         out["config"]["solver_iterations_last_step"] = s.last_iterations
-    skip = args.developed if args.developed is not None else (600 if (not iisph and not args.reference_order) else 0)
-    if skip > 0 and not iisph:
-        out["developed"] = developed_record(s, capi, n, skip, args.developed_steps, args.warmup + args.steps, bpp, real_bytes, torch)
+    if not iisph:
+        # the state of the flow the timed region ran in, at its two ends; cfl_ok: the fixed dt stayed inside the reference's own
+        # CFL rule (sph.cpp:217-231: dt <= 0.4 h / (c_s + |v|max)) through the window, i.e. the timed steps integrate a stable flow
+        out["developed"] = {"first_step": spin_up + args.warmup, "steps": args.steps, "ms_per_step": ms_per_step,
+                            "stage_ms": {k: v[0] / max(1, v[1]) for k, v in warm.items()}, "at_start": before, "at_end": after,
+                            "vmax": after["vmax"], "cfl_dt_limit": min(before["cfl_dt_limit"], after["cfl_dt_limit"]), "dt": after["dt"]}
+        out["cfl_ok"] = bool(out["developed"]["cfl_dt_limit"] >= after["dt"])
+        if resting:
+            out["resting"] = resting
     if not args.no_cpu_baseline and not iisph:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

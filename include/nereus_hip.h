@@ -8,6 +8,7 @@
  * state, one call per update().  It is what nereus_amd/host/ (our Nereus::SPH / Nereus::IISPH) and bench.py
  * use; INTEGRATION.md maps every reference entry point to its replacement.
  *
+ * The library reads NO environment variables: every switch that changes which kernels run is an NRS_FLAG_* bit of nrs_config.flags.
  * Conventions: every nrs_* call returns 0 on success, a negative NRS_E_* code otherwise, and
  * nrs_last_error() gives the message (no exceptions cross the ABI).  The caller owns host buffers,
  * the library owns device buffers.  A context is bound to one HIP device and one stream; it is not
@@ -87,6 +88,13 @@ enum {
                                            on the ORDER of the input arrays: the same particles permuted differ by centimetres
                                            after four steps.  Default off = the reference's behaviour; a
                                            multi-GPU slab run can only be compared with a single-domain run with this flag on. */
+    NRS_FLAG_NO_WALL_WORKGROUPS = 1u << 7, /* gather launches with ONE kind of workgroup: particles next to a wall are evaluated in place
+                                           by the general (boundary-aware) code instead of by the wall workgroups that walk the step's
+                                           wall list.  Same results bit for bit; slower on scenes with walls */
+    NRS_FLAG_STAGED_SCAN = 1u << 8,     /* SESPH fp32 Muller: the density launch is the LDS-STAGED scan (k_density_staged: one wavefront
+                                           per 64 consecutive sorted slots, row hulls by ballot + readlane, one z-plane of candidates
+                                           staged in LDS) instead of the quantised global-memory scan.  Same lists, same sums, bit for
+                                           bit; measured slower, kept as the north-star's literal kernel shape */
     NRS_FLAG_IISPH_INPLACE_P = 1u << 1, /* reserved: the reference's racy in-place Jacobi is NOT
                                            offered; P_l is always double-buffered */
 };

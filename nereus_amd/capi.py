@@ -22,6 +22,8 @@ FLAG_NO_SHARED_LISTS = 8
 FLAG_FULL_SORT = 16
 FLAG_FAST_ARITH = 32
 FLAG_IISPH_SELF_BY_SLOT = 64
+FLAG_NO_WALL_WORKGROUPS = 128
+FLAG_STAGED_SCAN = 256
 E_NOTREADY = -6
 STAT_MOVERS, STAT_HIT_OVERFLOW, STAT_HIT_MEAN, STAT_HIT_MAX, STAT_UNSTAGED = 0, 1, 2, 3, 4
 

@@ -75,16 +75,24 @@ template <typename R, typename T4> static int boundary_volumes(const void *bi4, 
 {
     const T4 *hb = (const T4 *)bi4;
     double lo[3] = {hb[0].x, hb[0].y, hb[0].z}, hi[3] = {hb[0].x, hb[0].y, hb[0].z};
-    for (uint64_t i = 1; i < nb; ++i) {
+    for (uint64_t i = 0; i < nb; ++i) {
         const double c[3] = {hb[i].x, hb[i].y, hb[i].z};
+        // (a NaN / inf coordinate would make the cell index of that particle undefined behaviour, here and on the device)
+        if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]))) return fail(NRS_E_INVALID, "boundary particle with a non-finite coordinate");
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
     }
     BGrid<R> g;
     g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.h = h;
     uint64_t dims[3];
-    for (int a = 0; a < 3; ++a) dims[a] = (uint64_t)std::floor((hi[a] - lo[a]) / h) + 1;
+    for (int a = 0; a < 3; ++a) {
+        const double d = std::floor((hi[a] - lo[a]) / h) + 1.0;
+        if (!(d >= 1.0 && d <= 2147483648.0)) return fail(NRS_E_INVALID, "boundary AABB spans more than 2^31 cells of size h along one axis");
+        dims[a] = (uint64_t)d;
+    }
+    // every factor is <= 2^31: the first product cannot wrap, the second is checked before it is formed
+    if (dims[0] * dims[1] > (1ull << 31) || dims[0] * dims[1] * dims[2] > (1ull << 31))
+        return fail(NRS_E_INVALID, "boundary AABB spans more than 2^31 cells of size h");
     const uint64_t cells = dims[0] * dims[1] * dims[2];
-    if (cells == 0 || cells > (1ull << 31)) return fail(NRS_E_INVALID, "boundary AABB spans more than 2^31 cells of size h");
     g.gx = (uint32_t)dims[0]; g.gy = (uint32_t)dims[1]; g.gz = (uint32_t)dims[2];
     const double kpoly = 315.0 / (64.0 * 3.14159265358979323846 * std::pow(h, 9));
     const uint32_t n = (uint32_t)nb, nbk = (n + 255u) / 256u;
@@ -136,6 +144,7 @@ extern "C" int nrs_boundary_volumes(int device, int precision, const void *bi4, 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NRS_E_NODEVICE, "no HIP device available: libnereus_hip has no CPU fallback");
     if (device >= ndev) return fail(NRS_E_INVALID, "device ordinal out of range");
-    if (device >= 0) HIPCHK(hipSetDevice(device));
+    DeviceScope scope(device); // the caller's current device is restored on return
+    if (!scope.ok()) return fail(NRS_E_HIP, "hipSetDevice failed");
     return precision == 32 ? boundary_volumes<float, float4>(bi4, nb, h, vbi) : boundary_volumes<double, double4>(bi4, nb, h, vbi);
 }

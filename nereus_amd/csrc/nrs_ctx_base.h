@@ -53,6 +53,20 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// hipSetDevice for the duration of a call that is not bound to a context's own device bookkeeping (nrs_boundary_volumes,
+// nrs_eval_smoothing): the caller's current device is put back on every way out.  device < 0 = stay on the current device.
+struct DeviceScope {
+    int prev = -1;
+    bool good = true;
+    explicit DeviceScope(int device)
+    {
+        if (device < 0) return;
+        good = hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess;
+        if (!good) prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    bool ok() const { return good; }
+};
 
 struct CtxBase {
     virtual ~CtxBase() {}

@@ -34,10 +34,8 @@ using SortCfg10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::d
 static inline hipError_t sort_pairs(void *tmp, size_t &bytes, rocprim::double_buffer<uint32_t> &k, rocprim::double_buffer<uint32_t> &v,
                                     size_t n, unsigned bits, hipStream_t stream)
 {
-    static const int mode = getenv("NEREUS_SORT_BITS") ? atoi(getenv("NEREUS_SORT_BITS")) : 0;
-    const bool wide = mode != 8; // NEREUS_SORT_BITS=8 forces rocPRIM's default 8-bit passes
-    if (wide && bits > 24 && bits <= 27) return rocprim::radix_sort_pairs<SortCfg9>(tmp, bytes, k, v, n, 0u, bits, stream);
-    if (wide && bits > 27 && bits <= 30) return rocprim::radix_sort_pairs<SortCfg10>(tmp, bytes, k, v, n, 0u, bits, stream);
+    if (bits > 24 && bits <= 27) return rocprim::radix_sort_pairs<SortCfg9>(tmp, bytes, k, v, n, 0u, bits, stream);
+    if (bits > 27 && bits <= 30) return rocprim::radix_sort_pairs<SortCfg10>(tmp, bytes, k, v, n, 0u, bits, stream);
     return rocprim::radix_sort_pairs(tmp, bytes, k, v, n, 0u, bits, stream);
 }
 
@@ -128,8 +126,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool wallListed = false; // this step's gathers run with wall workgroups
     bool deferWalls() const
     {
-        static const bool allow = !(getenv("NEREUS_WALL_PASS") && atoi(getenv("NEREUS_WALL_PASS")) == 0);
-        return allow && nearBitsValid && nb != 0 && (!iisph() || iisph_lists()) && !refOrder() && lists_ok();
+        return !(cfg.flags & NRS_FLAG_NO_WALL_WORKGROUPS) && nearBitsValid && nb != 0 && (!iisph() || iisph_lists()) && !refOrder() && lists_ok();
     }
     WallList wall_view() const { return WallList{nearBits.as<uint32_t>(), hashCur, wallList.as<uint32_t>(), wallScalars.as<uint32_t>() + 1, wallMask.as<unsigned long long>()}; }
     // this step's wall list: tile counts (reorder kernel) -> two-level scan (the re-sort's scan kernel) -> stable compaction
@@ -150,12 +147,11 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     // LDS-staged density scan (nrs_kernels_staged.h): fp32 SESPH on power-of-two grids.  Measured at 10 M particles it is
     // SLOWER than the global-memory scan in the exact arithmetic (0.84 vs 0.71 ms: the kernel is bound by vector-instruction
     // issue, not by the latency the staging removes), and since the quantised scan (0.52 ms) also slower than the
-    // exact path in its own fast arithmetic (0.70-0.88 ms): it runs only when NEREUS_STAGED=1 asks for it.
+    // exact path in its own fast arithmetic (0.70-0.88 ms): it runs only when NRS_FLAG_STAGED_SCAN asks for it.
     bool stagedScan() const
     {
-        static const int mode = getenv("NEREUS_STAGED") ? atoi(getenv("NEREUS_STAGED")) : -1;
-        if (mode == 0 || !std::is_same<R, float>::value || iisph() || refOrder() || P.numCells > (1u << 30)) return false;
-        return mode == 1 && KSET == KS_MULLER && lists_ok();
+        if (!(cfg.flags & NRS_FLAG_STAGED_SCAN) || !std::is_same<R, float>::value || iisph() || refOrder() || P.numCells > (1u << 30)) return false;
+        return KSET == KS_MULLER && lists_ok();
     }
     // fast arithmetic (reciprocals, rsq, fused multiply-adds) in the FORCE walk: fp32 Muller SESPH on the production kernels with
     // shared lists; the density kernel (exact) leaves the (p/rho^2, 1/rho) pairs it needs; everything else keeps IEEE arithmetic
@@ -175,8 +171,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     bool splitClearedCells = false; // this step's k_resort_split also reset the cell table
     uint64_t rsSteps = 0, rsFallbacks = 0;
     double lastMovers = -1.0; // mover count of the last coherent re-sort
-    uint32_t rsMaxPct = getenv("NEREUS_RESORT_MAX_PCT") ? (uint32_t)atoi(getenv("NEREUS_RESORT_MAX_PCT")) : RESORT_MAX_MOVER_PCT;
-    bool few_movers(uint64_t M, uint64_t N) const { return M * 100ull <= N * (uint64_t)rsMaxPct; }
+    bool few_movers(uint64_t M, uint64_t N) const { return M * 100ull <= N * (uint64_t)RESORT_MAX_MOVER_PCT; }
     // slab decomposition
     bool slabOn = false;
     SlabCfg slab = {INT_MIN / 2, INT_MAX / 2, 2};
@@ -391,8 +386,19 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         return NRS_OK;
     }
 
+    // a host-driven IISPH step (nrs_iisph_predict .. nrs_iisph_finish) holds hit lists, factors and a halo budget that belong to the
+    // arrays, grid and cuts it was predicted on: everything that would change those is refused until it is finished (or abandoned
+    // by uploading particles)
+    int refuse_mid_iisph(const char *what) const
+    {
+        if (!iisphPhase) return NRS_OK;
+        char buf[200];
+        snprintf(buf, sizeof(buf), "%s while a host-driven IISPH step is in progress (nrs_iisph_finish first, or upload particles to abandon it)", what);
+        return fail(NRS_E_STATE, buf);
+    }
     int set_params(const void *params) override
     {
+        NRSCHK(refuse_mid_iisph("nrs_set_params"));
         Params<R> q;
         std::memcpy(&q, params, sizeof(q));
         // the keys the fused force kernel left for the next step depend on the grid only (a new time step or viscosity
@@ -443,6 +449,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (first + count > n) n = first + count;
         if (slabOn) nOwned = n; // (until the next partition says otherwise)
         midStep = false;
+        iisphPhase = 0; iisphIter = 0; // new particles abandon a host-driven IISPH step that was in progress
         hashReady = false; rsPending = false; rsCountKnown = false;
         slotOrderValid = false; classifiedValid = false;
         return NRS_OK;
@@ -453,6 +460,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
         NRSCHK(compact_holes());
         if (nn != n) { hashReady = false; rsPending = false; rsCountKnown = false; slotOrderValid = false; classifiedValid = false; }
+        if (nn != n) { iisphPhase = 0; iisphIter = 0; } // (the hit lists of a predicted step belong to the old particle set)
         n = nn;
         if (slabOn) nOwned = n;
         return NRS_OK;
@@ -518,6 +526,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
 
     int set_boundaries(const void *bi4, const void *vbi, uint64_t nbNew, int update_grid) override
     {
+        NRSCHK(refuse_mid_iisph("nrs_set_boundaries"));
         if (nbNew > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "too many boundary particles (max 2^27-1)");
         if (nbNew && (!bi4 || !vbi)) return fail(NRS_E_INVALID, "bi4/vbi is NULL");
         nb = nbNew;
@@ -778,8 +787,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_begin(NRS_STAGE_SORT));
         const uint32_t nTiles = nblocks(N);
         NRSCHK(launch_resort_scan(nTiles, false));
-        static const bool allowClear = !(getenv("NEREUS_SPLIT_CLEAR") && atoi(getenv("NEREUS_SPLIT_CLEAR")) == 0);
-        const bool clear = allowClear && (uint64_t)P.numCells > 8ull * n; // the step's cell-table reset rides along (see step())
+        const bool clear = (uint64_t)P.numCells > 8ull * n; // the step's cell-table reset rides along (see step())
         hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(), offsets_movers(),
                            rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, clear ? cellStart.as<uint32_t>() : (uint32_t *)nullptr);
         splitClearedCells = clear;
@@ -836,9 +844,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             const bool resort = rsMovers.p && !slabOn && (uint64_t)N >= RESORT_MIN_PARTICLES;
             // slab runs: the next partition's classification rides in the same launch (k_slab_count and most of
             // k_slab_scatter then have nothing left to do)
-            static const bool allowFusedSlab = !(getenv("NEREUS_SLAB_FUSED") && atoi(getenv("NEREUS_SLAB_FUSED")) == 0) &&
-                                               !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
-            const bool classify = rsMovers.p && slabOn && allowFusedSlab && (uint64_t)N >= RESORT_MIN_PARTICLES;
+            const bool classify = rsMovers.p && slabOn && (uint64_t)N >= RESORT_MIN_PARTICLES;
             if (resort || classify) NRSCHK(clean_tile_counts());
             fo.prevHash = (resort || classify) ? hashCur : nullptr;
             fo.tileMovers = (resort || classify) ? rsTileMovers.as<uint32_t>() : nullptr;
@@ -1150,6 +1156,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     {
         // IISPH: every solver iteration consumes two cells of halo validity, the predict stages three and the pressure force one
         // (DESIGN.md §5): 2 iterations — the reference's minimum — need 8 cells
+        NRSCHK(refuse_mid_iisph("nrs_slab_configure"));
         if (iisph() && halo < 8) return fail(NRS_E_INVALID, "IISPH slabs need a halo of at least 8 cells (2 * iterations + 4)");
         if (halo < 2) return fail(NRS_E_INVALID, "halo must be >= 2 cells (one cell for the density of the ring + one)");
         if ((long long)hi - lo < 2ll * halo) return fail(NRS_E_INVALID, "slab narrower than two halos");
@@ -1179,11 +1186,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     static constexpr int WINDOW_SLACK = 8;
     bool choose_window(int lo, int hi, int halo, bool force)
     {
-        static const bool allow = !(getenv("NEREUS_SLAB_LOCAL_GRID") && atoi(getenv("NEREUS_SLAB_LOCAL_GRID")) == 0);
         const long long GX = (long long)PU.gridSize[0];
         const bool pow2 = is_pow2(PU.gridSize[0]) && is_pow2(PU.gridSize[1]) && is_pow2(PU.gridSize[2]);
         long long a = std::max<long long>(0, (long long)lo - halo - 2), b = std::min<long long>(GX, (long long)hi + halo + 2);
-        if (!allow || !pow2 || b <= a) {
+        if (!pow2 || b <= a) {
             const bool changed = winW != 0;
             winW = 0; winBase = 0;
             return changed;
@@ -1276,8 +1282,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 // the fused force kernel left the new keys per slot
                 const bool resort = rsMovers.p && slotOrderValid && hashCur && hashNext && hashNext != hashCur;
                 // ... and then the owned particles need not be moved at all (in-place partition, see k_slab_scatter)
-                static const bool allowInplace = !(getenv("NEREUS_SLAB_INPLACE") && atoi(getenv("NEREUS_SLAB_INPLACE")) == 0);
-                inplace = resort && allowInplace && (uint64_t)N >= RESORT_MIN_PARTICLES;
+                inplace = resort && (uint64_t)N >= RESORT_MIN_PARTICLES;
                 hipLaunchKernelGGL((k_slab_count<R>), dim3(nbk), dim3(SLAB_BLOCK), 0, stream, P, slab, posA.as<T4>(), N,
                                    slabCounts.as<uint32_t>(), nbk, resort ? hashCur : (const uint32_t *)nullptr,
                                    resort ? hashNext : (const uint32_t *)nullptr);
@@ -1371,6 +1376,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int slab_unpack(const void *recvL, const void *recvR, uint64_t mcap) override
     {
         NRSCHK(validate("nrs_slab_unpack"));
+        NRSCHK(refuse_mid_iisph("nrs_slab_unpack"));
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
         uint32_t hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
         if (recvL) HIPCHK(hipMemcpyAsync(hL, recvL, 16, hipMemcpyDeviceToHost, stream));
@@ -1432,9 +1438,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     // write latency, where hipEventSynchronize on an otherwise idle host thread was measured to cost ~0.1 ms per step.
     int wait_mover_count(uint32_t *M)
     {
-        static const bool poll = !(getenv("NEREUS_RS_POLL") && atoi(getenv("NEREUS_RS_POLL")) == 0);
         volatile uint64_t *w = (volatile uint64_t *)rsHostTotal;
-        if (poll) {
+        {
             for (uint64_t spins = 0;; ++spins) {
                 const uint64_t v = *w;
                 if ((uint32_t)(v >> 32) == rsSeq) { *M = (uint32_t)v; return NRS_OK; }

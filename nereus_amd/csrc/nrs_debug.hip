@@ -40,9 +40,11 @@ template <typename R> static int eval_smoothing(int which, uint64_t n, const voi
 {
     DevBuf dr, ds, dout;
     const size_t bytes = sizeof(R) * 3 * n;
-    NRSCHK(dr.alloc(bytes)); NRSCHK(dout.alloc(bytes));
-    if (s3) NRSCHK(ds.alloc(bytes));
     auto done = [&](int rc) { dr.release(); ds.release(); dout.release(); return rc; };
+    int rc = dr.alloc(bytes); // (every way out goes through done(): a failed second allocation must not leak the first)
+    if (rc == NRS_OK) rc = dout.alloc(bytes);
+    if (rc == NRS_OK && s3) rc = ds.alloc(bytes);
+    if (rc != NRS_OK) return done(rc);
     if (hipMemcpy(dr.p, r3, bytes, hipMemcpyHostToDevice) != hipSuccess) return done(fail(NRS_E_HIP, "hipMemcpy"));
     if (s3 && hipMemcpy(ds.p, s3, bytes, hipMemcpyHostToDevice) != hipSuccess) return done(fail(NRS_E_HIP, "hipMemcpy"));
     hipLaunchKernelGGL((k_eval_smoothing<R>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, nullptr, which, (uint32_t)n, dr.as<R>(),

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
     I.forcesAdv[i] = mk4<R>(force_adv, (R)0.0);
     I.velAdv[i] = mk4<R>(vel_adv, (R)0.0);
     watch_finite<R>(I.nonFinite, vel_adv);
+    // a particle with a NaN / inf / absurd coordinate (a caller's bug) is in nobody's hit list, while the reference's loops without
+    // a cut-off multiply its NaN distance into their sums: such a step is repeated in reference order as well
+    watch_finite<R>(I.nonFinite, pos1);
     if (hc.over) { // per-cell walk of the reference-order kernel for this particle
         const I3 gp = calcGridPos<R>(P, pos1);
         for (int z = -1; z <= 1; z++)

@@ -26,7 +26,7 @@ namespace nrs {
 constexpr int RESORT_GROUP = 1024;              // tiles per scan workgroup
 constexpr uint64_t RESORT_MIN_PARTICLES = 32768; // below this the full sort is launch-bound either way
 constexpr uint32_t RESORT_MAX_MOVER_PCT = 50;    // more movers than this share of N: full radix sort (measured break-even,
-                                                 // DESIGN.md §4; NEREUS_RESORT_MAX_PCT overrides it for experiments)
+                                                 // DESIGN.md §4)
 
 // Exclusive scan of the per-tile mover counts, two levels: every workgroup scans RESORT_GROUP counts (coalesced; the
 // counts are reset to 0 for the next step's atomics) and the last one to finish scans the group totals.

@@ -575,7 +575,7 @@ static inline void launch_density_staged(hipStream_t stream, const Params<float>
     const dim3 g((n + STG_WAVE - 1) / STG_WAVE), b(STG_WAVE);
     HitBuffer hb = {nullptr, nullptr, 0};
     if (share) hb = *share;
-    static const unsigned pad = getenv("NEREUS_DBG_LDS_PAD_S") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD_S")) : 0u; // occupancy experiment
+    constexpr unsigned pad = NRS_DBG_LDS_PAD; // occupancy experiment (compile-time, see nrs_kernels_tiled.h)
     if (fast && KSET == KS_MULLER) {
         if (share) hipLaunchKernelGGL((k_density_staged<KS_MULLER, HAS_B, true, true>), g, b, pad, stream, P, G, thr, sPos, dens, pres, fq, hb, n);
         else hipLaunchKernelGGL((k_density_staged<KS_MULLER, HAS_B, false, true>), g, b, 0, stream, P, G, thr, sPos, dens, pres, fq, hb, n);

@@ -69,6 +69,12 @@ NRS_DEV double bcast_lane(double v, int srcLane)
 #ifndef NRS_FORCE_PAIRS
 #define NRS_FORCE_PAIRS 1 // the list-driven force kernel gathers (p / rho^2, m / rho) pairs written by the density kernel (HitBuffer::pairs)
 #endif
+#ifndef NRS_DBG_LDS_PAD
+#define NRS_DBG_LDS_PAD 0 // bytes of dynamic LDS added to every density workgroup (occupancy experiments only)
+#endif
+#ifndef NRS_DBG_LDS_PAD_F
+#define NRS_DBG_LDS_PAD_F 0 // ... to every fused force workgroup
+#endif
 #ifndef QP_WALK
 #define QP_WALK 4 // list entries whose exact positions are gathered together in density_from_superset
 #endif
@@ -330,8 +336,11 @@ template <typename R> struct Sweep {
                     uint32_t a = (s0 != CELL_EMPTY) ? s0 : ((s1 != CELL_EMPTY) ? s1 : s2);
                     uint32_t b = (s2 != CELL_EMPTY) ? en[y][2] : ((s1 != CELL_EMPTY) ? en[y][1] : en[y][0]);
                     if (a == CELL_EMPTY) a = b = 0;
-                    lo[y] = a;
-                    nT[y] = run_ok<R>(G, a, b) ? b - a : 0u;
+                    // a run that fails the guard (stale / corrupt table) is neither swept nor PREFETCHED: its loads go to slot 0
+                    // (invariant otherwise: a <= b <= nSorted <= capacity, and qpos has QSLOTS slots of padding behind capacity)
+                    const bool ok = run_ok<R>(G, a, b);
+                    lo[y] = ok ? a : 0u;
+                    nT[y] = ok ? b - a : 0u;
                 }
                 Q2 c[3][QP_PRE];
 #pragma unroll
@@ -1082,8 +1091,9 @@ static inline void launch_density_tiled(hipStream_t stream, const Params<R> &P, 
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
     HitBuffer hb = {nullptr, nullptr, 0};
     const WallList none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    // occupancy experiment: extra dynamic LDS per workgroup lowers the workgroups per CU
-    static const unsigned pad = getenv("NEREUS_DBG_LDS_PAD") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD")) : 0u;
+    // occupancy experiment (tools/occupancy_sweep.sh builds variants with -DNRS_DBG_LDS_PAD=bytes): extra dynamic LDS per
+    // workgroup lowers the workgroups per CU
+    constexpr unsigned pad = NRS_DBG_LDS_PAD;
     if (share) {
         hb = *share;
         if (HAS_B && wall) {
@@ -1132,7 +1142,7 @@ static inline void launch_forces_tiled(hipStream_t stream, const Params<R> &P, c
     fo.slab = SlabCfg{0, 0, 0};
     if (fused) fo = *fused;
     const dim3 g((n + BLOCK - 1) / BLOCK), b(BLOCK);
-    static const unsigned padF = getenv("NEREUS_DBG_LDS_PAD_F") ? (unsigned)atoi(getenv("NEREUS_DBG_LDS_PAD_F")) : 0u; // occupancy experiment
+    constexpr unsigned padF = NRS_DBG_LDS_PAD_F; // occupancy experiment
     const WallList none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (lists && HAS_B && wall) { // wall workgroups + interior workgroups without the boundary code (see k_density_tiled)
         const uint32_t wb = wall_blocks(g.x);

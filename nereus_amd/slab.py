@@ -25,6 +25,12 @@ from .params import default_params, update_grid
 
 HALO_CELLS = 2
 IISPH_HALO_CELLS = 8   # 2 * solver iterations + 4 (include/nereus_hip.h, nrs_iisph_*): the reference's minimum of 2 iterations
+
+
+def iisph_halo_cells(max_iters):
+    """Halo width (cells) that keeps an IISPH slab step exact for up to `max_iters` solver iterations: density 1 + displacement /
+    advection 2 + 2 per Jacobi iteration + pressure force 1.  The reference's loop runs at least twice."""
+    return 2 * max(2, int(max_iters)) + 4
 NO_CUT_LO = -(1 << 29)
 NO_CUT_HI = (1 << 29)
 
@@ -81,7 +87,11 @@ def new_cuts(hist, old, halo, move_budget):
 class HipSlabEngine:
     """Product engine: particles live in an nrs_ctx on this rank's GPU; buffers are torch CUDA tensors."""
 
-    def __init__(self, params, capacity, msg_capacity, cell_lo, cell_hi, device_index, halo=HALO_CELLS, iisph=False, flags=0):
+    def __init__(self, params, capacity, msg_capacity, cell_lo, cell_hi, device_index, halo=None, iisph=False, flags=0,
+                 iisph_max_iters=2):
+        """halo: cells exchanged per side; None = 2 for SESPH, iisph_halo_cells(iisph_max_iters) for IISPH.  An IISPH slab run can
+        do at most (halo - 4) // 2 solver iterations per step (`max_iters`; SlabDriver.iisph_step stops there and counts the step
+        as truncated, like nrs_set_max_iterations on a single domain) — size the halo from the iteration budget."""
         import torch
 
         from . import capi
@@ -95,6 +105,9 @@ class HipSlabEngine:
         self.stream = torch.cuda.Stream(device=self.device)
         assert self.stream.cuda_stream != 0
         self.iisph = bool(iisph)
+        if halo is None:
+            halo = iisph_halo_cells(iisph_max_iters) if iisph else HALO_CELLS
+        self.max_iters = (halo - 4) // 2 if iisph else None
         self.solver = capi.Solver(params, capacity, solver=capi.IISPH if iisph else capi.SESPH, device=device_index,
                                   stream=self.stream.cuda_stream, flags=flags)
         self.cell_lo, self.cell_hi, self.halo = cell_lo, cell_hi, halo
@@ -221,15 +234,25 @@ class SlabDriver:
             else:
                 self.engine.step(1)
 
-    def iisph_step(self):
+    truncated_steps = 0
+
+    def iisph_step(self, min_iters=2):
         """IISPH::update() over the slabs: pressureSolve's loop `while ((rho_avg - 1000) > 1 || l < 2)` (sph_cuda.cu:736-741)
         with rho_avg formed from the sums of ALL ranks — one two-scalar all-reduce per iteration, the reference's
-        thrust::reduce + host round trip (sph_cuda.cu:816-819) made global.  Returns the iteration count."""
+        thrust::reduce + host round trip (sph_cuda.cu:816-819) made global.  Returns the iteration count.
+        The halo width bounds the iterations a slab step can do exactly (engine.max_iters = (halo - 4) // 2, the same on every
+        rank): a step whose exit test still asks for more at that point is finished there and counted in `truncated_steps`
+        (the multi-GPU form of nrs_set_max_iterations) instead of failing on every rank and leaving the contexts mid-step.
+        min_iters: the reference's 2; tests raise it to drive more iterations than the reference's exit test ever asks for."""
         torch, dist, eng = self.torch, self.dist, self.engine
         real = np.float32 if not getattr(eng, "double", False) else np.float64
+        cap = getattr(eng, "max_iters", None)
         eng.iisph_predict()
         it, rho_avg = 0, real(0)
-        while (float(rho_avg) - 1000.0) > 1.0 or it < 2:
+        while (float(rho_avg) - 1000.0) > 1.0 or it < min_iters:
+            if cap is not None and it >= cap:
+                self.truncated_steps += 1
+                break
             s, c = eng.iisph_iterate()
             t = torch.tensor([s, float(c)], dtype=torch.float64)
             dev = getattr(eng, "device", None) if dist.get_backend(self.group) == "nccl" else None
@@ -340,15 +363,16 @@ def bench_main(args, lattice, rank, world, local_rank):
         dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     iisph = getattr(args, "solver", "sesph") == "iisph"
-    halo = IISPH_HALO_CELLS if iisph else HALO_CELLS
+    max_iters = int(getattr(args, "iisph_max_iters", 2) or 2)
+    halo = iisph_halo_cells(max_iters) if iisph else HALO_CELLS
     params = default_params(1 if iisph else 0)
     t_gen = time.perf_counter()
     p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
     t_gen = time.perf_counter() - t_gen
     nx, ny, nz = lattice
     msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos))
-    if iisph:  # wider halo (8 cells instead of 2): four times the halo particles per message
-        msg_cap, cap = 4 * msg_cap, cap + 6 * msg_cap
+    if iisph:  # wider halo (8 cells instead of 2 for two iterations): halo / 2 times the halo particles per message
+        msg_cap, cap = (halo // HALO_CELLS) * msg_cap, cap + (halo - HALO_CELLS) * msg_cap
     eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank, halo=halo, iisph=iisph)
     eng.load(pos, vel, bi, vbi)
     drv = SlabDriver(eng, rank, world, stage_through_host=(backend != "nccl"))
@@ -440,6 +464,7 @@ def bench_main(args, lattice, rank, world, local_rank):
             "parallelism": "slab x%d" % world,
             "message_bytes_per_direction": eng.msg_bytes,
             "sort": dict(zip(("coherent_resort_steps", "fell_back_to_full_sort"), eng.solver.resort_stats())),
+            **({"iisph_max_iters_per_step": eng.max_iters, "iisph_truncated_steps": drv.truncated_steps} if iisph else {}),
         },
         "roofline": {
             "bound": "hbm", "kernel": "forces+integrate+hash (one fused launch)" if fused else dominant, "achieved": achieved,

@@ -222,6 +222,12 @@ struct Sim {
     int selfBySlot = 0;      /* Q5 off: exclude the particle itself (j == own slot) instead of the thread id; the result then no
                                 longer depends on the ORDER of the input arrays (used to compare slab runs with single-domain ones) */
     int threads = 1;
+    int surf = USE_SURFACE_TENSION; /* the reference's compile-time USE_SURFACE_TENSION (CMakeLists.txt:28, sph_kernel_impl.cuh:535-548) as a
+                                run-time switch, so that one build checks both instantiations of the product (orc_set_surface_tension) */
+    int taitDouble7 = 0;     /* Tait pressure (sph_kernel_impl.cuh:426): 0 = glibc powf(x, 7), what g++ gives the reference on the host;
+                                1 = x^7 formed in double and rounded ONCE to float — what the device evaluates (nrs_math.h pow7f).  The two
+                                differ by 1 ulp in ~0.1 % of the values; mode 1 lets the N-step bar measure the kernels instead of two
+                                pow conventions (tests name the mode they assert in) */
     SUint lastIters = 0;
     /* host */
     std::vector<SVec4> pos, vel;
@@ -306,6 +312,7 @@ struct Grid {
     const SUint *cellStart, *cellEnd, *bCellStart, *bCellEnd, *bindex;
     const SVec4 *bi;   const SReal *vbi;    /* unsorted boundary, indexed through bindex (SESPH helpers) */
     const SVec4 *sbi;  const SReal *svbi;   /* sorted boundary, indexed directly (IISPH helpers) */
+    int surf;                               /* USE_SURFACE_TENSION */
 };
 
 /* computeCellDensity / computeBoundaryCellDensity: sph_kernel_impl.cuh:290-360 */
@@ -406,17 +413,15 @@ static inline void cellForces(const Grid &G, SVec3 *fpres, SVec3 *fvisc, SVec3 *
                 const SReal a = dot(p1p2, kvisco_grad);
                 const SReal b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
                 *fvisc = *fvisc + (m2 / dens2 * v1v2 * (a / b));
-#if USE_SURFACE_TENSION == 1
-                SVec3 ai = mk3(0.0, 0.0, 0.0);
-                const SReal r2 = dot(p1p2, p1p2);
-                if (r2 > diameter2)
-                    ai = ai - (kappa / pm * pm * p1p2 * kernel);
-                else
-                    ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
-                *fsurf = *fsurf + ai;
-#else
-                (void)kernel; (void)kernel_diameter; (void)diameter2;
-#endif
+                if (G.surf) { /* #if USE_SURFACE_TENSION == 1, sph_kernel_impl.cuh:535-548 */
+                    SVec3 ai = mk3(0.0, 0.0, 0.0);
+                    const SReal r2 = dot(p1p2, p1p2);
+                    if (r2 > diameter2)
+                        ai = ai - (kappa / pm * pm * p1p2 * kernel);
+                    else
+                        ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+                    *fsurf = *fsurf + ai;
+                }
             }
         }
     }
@@ -460,7 +465,13 @@ static void k_densityPressure(Sim &S, const Grid &G)
     for (SUint t = 0; t < S.N; ++t) {
         const SUint slot = S.index[t];
         SReal dens = densityOf(G, slot, S.sPos.data());
-        const SReal pressure = P.gasStiffness * (powf(dens / P.restDensity, 7) - 1);
+        SReal pressure;
+        if (S.taitDouble7) {
+            const double x = (double)(float)(dens / P.restDensity), x2 = x * x, x4 = x2 * x2;
+            pressure = P.gasStiffness * ((float)(x4 * x2 * x) - 1);
+        } else {
+            pressure = P.gasStiffness * (powf(dens / P.restDensity, 7) - 1);
+        }
         S.sDens[slot] = dens;
         S.sPres[slot] = pressure;
     }
@@ -919,6 +930,7 @@ static Grid makeGrid(Sim &S)
     G.bindex = S.bindex.data();
     G.bi = S.bi.data(); G.vbi = S.vbi.data();
     G.sbi = S.sbi.data(); G.svbi = S.svbi.data();
+    G.surf = S.surf;
     return G;
 }
 
@@ -1173,6 +1185,8 @@ void orc_set_mode(void *h, int jacobi, int threads)
     S->threads = threads < 1 ? 1 : threads;
 }
 void orc_set_self_by_slot(void *h, int on) { ((Sim *)h)->selfBySlot = on; }
+void orc_set_surface_tension(void *h, int on) { ((Sim *)h)->surf = on ? 1 : 0; }
+void orc_set_tait_mode(void *h, int double7) { ((Sim *)h)->taitDouble7 = double7 ? 1 : 0; }
 void orc_set_particles(void *h, const SReal *pos4, const SReal *vel4, const SReal *pres, SUint n)
 {
     Sim *S = (Sim *)h;

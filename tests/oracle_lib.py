@@ -46,6 +46,8 @@ def _load(double, kernel_set):
     lib.orc_get_params.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.orc_set_self_by_slot.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_set_surface_tension.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_set_tait_mode.argtypes = [C.c_void_p, C.c_int]
     lib.orc_set_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
     lib.orc_set_boundaries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
     lib.orc_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -73,7 +75,8 @@ def _ptr(a):
 class Oracle:
     """One simulated solver (mirrors the nrs_ctx API of the HIP library so tests read symmetrically)."""
 
-    def __init__(self, params=None, double=False, kernel_set=1, solver=SESPH, threads=1, jacobi=True, self_by_slot=False):
+    def __init__(self, params=None, double=False, kernel_set=1, solver=SESPH, threads=1, jacobi=True, self_by_slot=False,
+                 surface_tension=True, tait="powf"):
         self.double, self.kernel_set, self.solver = bool(double), int(kernel_set), solver
         self.real = np.float64 if double else np.float32
         self.lib = _load(double, kernel_set)
@@ -84,6 +87,13 @@ class Oracle:
         self.lib.orc_set_mode(self.h, int(jacobi), int(threads))
         if self_by_slot:  # SURVEY Q5 switched off: order-independent IISPH (see nereus_oracle.cpp, Sim::selfBySlot)
             self.lib.orc_set_self_by_slot(self.h, 1)
+        if not surface_tension:  # USE_SURFACE_TENSION=0 (CMakeLists.txt:28, sph_kernel_impl.cuh:535-548)
+            self.lib.orc_set_surface_tension(self.h, 0)
+        # Tait x^7: "powf" = glibc powf, what g++ gives the reference on the host (default);
+        # "double7" = formed in double, rounded once to float, what the device evaluates (nrs_math.h pow7f)
+        assert tait in ("powf", "double7")
+        if tait == "double7":
+            self.lib.orc_set_tait_mode(self.h, 1)
 
     def __del__(self):
         try:

@@ -21,7 +21,7 @@ def _one_line(out):
 @pytest.mark.gpu
 def test_bench_line_single_gpu(hip_lib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "40,40,40", "--steps", "4", "--warmup", "2",
-                        "--developed", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--spin-up", "60", "--resting-steps", "10"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_line(r.stdout)
     for k in KEYS + ("cpu_baseline",):
@@ -35,6 +35,10 @@ def test_bench_line_single_gpu(hip_lib):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # round 3: the timed region follows an untimed spin-up under a CFL-respecting time step, both declared in the line
+    assert d["config"]["spin_up_steps"] == 60 and d["config"]["first_timed_step"] == 62 and abs(d["config"]["dt"] - 2.5e-4) < 1e-9
+    assert d["cfl_ok"] is True and d["developed"]["cfl_dt_limit"] >= d["developed"]["dt"]
+    assert d["developed"]["first_step"] == 62 and d["resting"]["first_step"] == 20 and d["resting"]["steps"] == 10
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

@@ -13,15 +13,12 @@ def test_random_scenes_production_equals_reference_order(hip_lib):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from fuzz_parity import one
 
-    failures, diverged = [], 0
-    for seed in range(9000, 9150):
-        r = one(seed)
-        if r == "diverged":
-            diverged += 1
-        elif r:
+    failures = []
+    for seed in range(9000, 9150):   # (covers 11 narrow-x grids, 9 far origins, 8 scenes with NaN / inf coordinates)
+        r = one(seed)                # ("diverged" is only returned under FUZZ_SKIP_NONFINITE=1: no seed is skipped here)
+        if r:
             failures.append(r)
     assert not failures, failures[:3]
-    assert diverged < 40
 
 
 @pytest.mark.gpu

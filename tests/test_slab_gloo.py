@@ -257,7 +257,7 @@ def _iisph_scene():
     return p, pos, vel
 
 
-def _iisph_worker(rank, world, port, steps, use_hip, outdir, by_slot):
+def _iisph_worker(rank, world, port, steps, use_hip, outdir, by_slot, force_iters=0, halo=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -272,7 +272,7 @@ def _iisph_worker(rank, world, port, steps, use_hip, outdir, by_slot):
     cut = int(np.median(cx)) + 1
     cuts = [slab.NO_CUT_LO, cut, slab.NO_CUT_HI]
     mine = (cx >= cuts[rank]) & (cx < cuts[rank + 1])
-    halo = slab.IISPH_HALO_CELLS
+    halo = halo or slab.IISPH_HALO_CELLS
     if use_hip:
         eng = slab.HipSlabEngine(p, 4 * len(pos), 2 * len(pos), cuts[rank], cuts[rank + 1], 0, halo=halo, iisph=True,
                                  flags=capi.FLAG_IISPH_SELF_BY_SLOT if by_slot else 0)
@@ -286,15 +286,16 @@ def _iisph_worker(rank, world, port, steps, use_hip, outdir, by_slot):
     for _ in range(steps):
         drv.exchange()
         moved += drv.last_counts[1] + drv.last_counts[3]
-        iters.append(drv.iisph_step())
+        iters.append(drv.iisph_step(min_iters=force_iters or 2))
     drv.finish()
     op, ov = eng.owned_state()
-    np.savez(os.path.join(outdir, "irank%d.npz" % rank), pos=op, vel=ov, iters=np.array(iters), moved=moved)
+    np.savez(os.path.join(outdir, "irank%d.npz" % rank), pos=op, vel=ov, iters=np.array(iters), moved=moved,
+             truncated=drv.truncated_steps)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _iisph_single(p, pos0, vel0, steps, by_slot):
+def _iisph_single(p, pos0, vel0, steps, by_slot, force_iters=0):
     from tests.oracle_lib import IISPH, Oracle
 
     o = Oracle(p, solver=IISPH, self_by_slot=by_slot)
@@ -302,7 +303,7 @@ def _iisph_single(p, pos0, vel0, steps, by_slot):
     o.set_boundaries(None, None)
     iters = []
     for _ in range(steps):
-        o.step(1)
+        o.step(1, max_iters=-force_iters)   # (negative: exactly that many iterations, nereus_oracle.cpp iisphStep)
         iters.append(o.last_iters)
     return o.get("pos"), o.get("vel"), iters
 
@@ -315,27 +316,28 @@ def _match(ref_pos, pos):
     return cKDTree(ref_pos[:, :3]).query(pos[:, :3])
 
 
-def _run_iisph(steps, use_hip, tmp_path, by_slot):
-    mp.spawn(_iisph_worker, args=(2, _free_port(), steps, use_hip, str(tmp_path), by_slot), nprocs=2, join=True)
+def _run_iisph(steps, use_hip, tmp_path, by_slot, force_iters=0, halo=None, single_iters=None):
+    mp.spawn(_iisph_worker, args=(2, _free_port(), steps, use_hip, str(tmp_path), by_slot, force_iters, halo), nprocs=2, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "irank%d.npz" % r)) for r in range(2)]
     pos = np.concatenate([q["pos"] for q in parts])
     vel = np.concatenate([q["vel"] for q in parts])
     p, pos0, vel0 = _iisph_scene()
     assert len(pos) == len(pos0), "particles lost or duplicated by the exchange"
     assert sum(int(q["moved"]) for q in parts) > 0
-    rp, rv, ref_iters = _iisph_single(p, pos0, vel0, steps, by_slot)
+    rp, rv, ref_iters = _iisph_single(p, pos0, vel0, steps, by_slot, force_iters if single_iters is None else single_iters)
     assert list(parts[0]["iters"]) == ref_iters == list(parts[1]["iters"])   # the global exit test, same count on every rank
+    _run_iisph.truncated = [int(q["truncated"]) for q in parts]
     d, idx = _match(rp, pos)
     return pos, vel, rp, rv, d, idx
 
 
-def _check_order_independent(steps, use_hip, tmp_path):
+def _check_order_independent(steps, use_hip, tmp_path, force_iters=0, halo=None, single_iters=None):
     """NRS_FLAG_IISPH_SELF_BY_SLOT (SURVEY Q5 off): the result no longer depends on the order of the arrays, so two slabs must
     reproduce the single-domain oracle particle for particle — this is the test of the halo width, of the pressure carried in
     vel.w and of the all-reduced exit test."""
     from tests.common import rel_err
 
-    pos, vel, rp, rv, d, idx = _run_iisph(steps, use_hip, tmp_path, True)
+    pos, vel, rp, rv, d, idx = _run_iisph(steps, use_hip, tmp_path, True, force_iters, halo, single_iters)
     assert len(np.unique(idx)) == len(pos) and d.max() < 1e-5
     assert rel_err(pos[:, :3], rp[idx, :3]) <= 1e-5
     assert rel_err(vel[:, :3], rv[idx, :3]) <= 1e-4
@@ -374,3 +376,30 @@ def test_iisph_slabs_hip_engine(tmp_path, hip_lib):
 @pytest.mark.gpu
 def test_iisph_slabs_reference_mode_hip_engine(tmp_path, hip_lib):
     _check_reference_mode(6, True, tmp_path)
+
+
+# The reference's exit test leaves its loop after two iterations on every scene tried (its relaxed Jacobi overshoots: the mean
+# corrected density goes far below 1000 after the second sweep), so longer solves are driven through SlabDriver.iisph_step's
+# min_iters — the halo budget 2 * iterations + 4 is what these tests are about.
+def test_iisph_slabs_four_iterations_gloo_cpu(tmp_path):
+    """Four solver iterations per step over a 12-cell halo (slab.iisph_halo_cells(4)) reproduce the single-domain oracle driven
+    through the same four iterations, particle for particle."""
+    from nereus_amd import slab
+
+    assert slab.iisph_halo_cells(4) == 12 and slab.iisph_halo_cells(1) == 8
+    _check_order_independent(3, False, tmp_path, force_iters=4, halo=12)
+    assert _run_iisph.truncated == [0, 0]
+
+
+@pytest.mark.gpu
+def test_iisph_slabs_four_iterations_hip_engine(tmp_path, hip_lib):
+    _check_order_independent(4, True, tmp_path, force_iters=4, halo=12)
+    assert _run_iisph.truncated == [0, 0]
+
+
+@pytest.mark.gpu
+def test_iisph_slabs_iteration_cap_is_reported_not_fatal(tmp_path, hip_lib):
+    """A step that wants more iterations than the halo supports (8 cells = 2 iterations, 4 asked for) is finished at the cap on
+    every rank and counted — the run goes on, the contexts are not left mid-step — and equals the single domain capped alike."""
+    _check_order_independent(4, True, tmp_path, force_iters=4, halo=8, single_iters=2)
+    assert _run_iisph.truncated == [4, 4]

@@ -5,7 +5,7 @@ O=gpurun_out/r02cfg; mkdir -p $O
 timeout -k 10 200 python bench.py --config C2 --no-cpu-baseline > $O/c2.json 2> $O/c2.err || { tail -3 $O/c2.err; exit 1; }
 timeout -k 10 300 python bench.py --solver iisph --config C3 --no-cpu-baseline > $O/c3.json 2> $O/c3.err || { tail -3 $O/c3.err; exit 1; }
 timeout -k 10 300 python bench.py --precision 64 --kernel-set monaghan --config C5 --no-cpu-baseline > $O/c5.json 2> $O/c5.err || { tail -3 $O/c5.err; exit 1; }
-NEREUS_BENCH_FORCE_SLAB=1 timeout -k 10 300 python bench.py --no-cpu-baseline --developed 0 > $O/slab1.json 2> $O/slab1.err || { tail -3 $O/slab1.err; exit 1; }
+NEREUS_BENCH_FORCE_SLAB=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/slab1.json 2> $O/slab1.err || { tail -3 $O/slab1.err; exit 1; }
 python - <<'PY'
 import json
 for n in ("c2","c3","c5","slab1"):

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_iisph; mkdir -p $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_WAVES TA_BUSY_avr SQ_WAVE_CYCLES -d $OUT/p -o p --output-format csv -- python3 $R/bench.py --solver iisph --config C2 --steps 6 --warmup 3 --developed 0 --no-cpu-baseline > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_WAVES TA_BUSY_avr SQ_WAVE_CYCLES -d $OUT/p -o p --output-format csv -- python3 $R/bench.py --solver iisph --config C2 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv,sys,glob,collections,re
 f=glob.glob("%s/p/**/*counter_collection.csv"%sys.argv[1],recursive=True)[0]

@@ -1,6 +1,8 @@
 """Randomised parity soak (GPU box): production kernels against the reference-order kernels, bit for bit, on random particle clouds
 with random grid geometry (cell size != h, anisotropic, origins far from the particles), optional random wall sheets; every 7th
-seed in fp64, every 3rd with the Monaghan kernels, every 5th IISPH.
+seed in fp64, every 3rd with the Monaghan kernels, every 5th IISPH; every 13th on a grid one or two cells wide in x (no quantised
+scan), every 17th with the grid origin more than 4096 cells away (beyond the quanta's error budget), every 19th with NaN / inf
+coordinates.
 usage: python tools/fuzz_parity.py [seeds=100] [first=0] [oracle]   (oracle: compare with the CPU oracle instead: keys bit-exact, floats
 within the parity tolerances)"""
 import os, sys
@@ -37,10 +39,14 @@ def make_scene(seed):
     cs = h * np.array([rng.choice([1.0, 1.0, 1.25, 0.62]), rng.choice([1.0, 1.0, 1.4]), rng.choice([1.0, 1.0, 0.8])])
     p["cellSize"][0] = cs.astype(real)
     lo = pos[:, :3].min(0) - rng.uniform(0.05, 40.0) * h
+    far = seed % 17 == 16   # the cloud sits > 4096 cells from the grid origin on one axis: outside the quantised scan's error budget
+    if far:                 # (QP_FAR) — owners are diverted to the wall workgroups' exact scan / the reference-order walk
+        lo[int(rng.integers(0, 3))] -= rng.uniform(4200, 9000) * cs.max()
     p["worldOrigin"][0] = lo.astype(real)
     gs = [int(2 ** np.ceil(np.log2(max(4, (pos[:, a].max() - lo[a]) / cs[a] + 2)))) for a in range(3)]
     if rng.random() < 0.3: gs[int(rng.integers(0, 3))] //= 2      # particles beyond the grid: wrap
     gs = [min(max(g, 4 if a == 0 else 1), 1024) for a, g in enumerate(gs)]
+    if seed % 13 == 12: gs[0] = int(rng.choice([1, 2]))          # x grids narrower than 4 cells: no quantised scan, no hit lists (qOk false)
     while gs[0] * gs[1] * gs[2] > 2 ** 27: gs[int(np.argmax(gs))] //= 2
     p["gridSize"][0] = gs; p["numCells"][0] = gs[0] * gs[1] * gs[2]
     bi = vbi = None
@@ -50,6 +56,10 @@ def make_scene(seed):
         bi[:, :3] = centre + rng.uniform(-0.5, 0.5, (nb, 3)) * ext
         bi[:, int(rng.integers(0, 3))] = real(pos[:, :3].min() + rng.uniform(0, 3) * h)   # a sheet
         vbi = rng.uniform(1e-5, 4e-5, nb).astype(real)
+    if seed % 19 == 18:   # a few particles with NaN / inf coordinates (a caller's bug must not take the device down)
+        k = rng.integers(0, n, 5)
+        pos[k[:3], int(rng.integers(0, 3))] = np.nan
+        pos[k[3:], int(rng.integers(0, 3))] = np.inf
     return dict(p=p, n=n, pos=pos, vel=vel, bi=bi, vbi=vbi, solver=solver, double=double, kset=kset, gs=gs, cs=cs, h=h)
 
 

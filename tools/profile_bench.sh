@@ -6,9 +6,9 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-x}; shift
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --developed 0 "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
 echo "trace done" >> $OUT/progress.log
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --developed 0 "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/fetch.log 2>&1
 echo "fetch done" >> $OUT/progress.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --developed 0 "$@" > $OUT/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/write.log 2>&1
 echo "write done" >> $OUT/progress.log

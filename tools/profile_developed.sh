@@ -7,9 +7,9 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-x}; shift
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 100 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 100 --warmup 700 --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
 echo "trace done" >> $OUT/progress.log
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --no-cpu-baseline "$@" > $OUT/fetch.log 2>&1
 echo "fetch done" >> $OUT/progress.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --developed 0 --no-cpu-baseline "$@" > $OUT/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 700 --no-cpu-baseline "$@" > $OUT/write.log 2>&1
 echo "write done" >> $OUT/progress.log

@@ -1,6 +1,6 @@
 """Regime of the north-star dam-break over time (GPU box): every CHUNK steps print ms/step of the chunk, neighbours per particle,
 mover fraction, full-sort fall-backs, max |v| and max density.  Documents what `developed` means at which step.
-usage: python tools/regime_probe.py [config] [total steps] [chunk]"""
+usage: python tools/regime_probe.py [config] [total steps] [chunk] [dt]   (dt: fixed time step in seconds, default = the reference's 1e-3)"""
 import json
 import os
 import sys
@@ -16,6 +16,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "NS"
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 250
 p = default_params(0)
+if len(sys.argv) > 4:
+    p["timestep"][0] = float(sys.argv[4])
 lat = scene.CONFIGS[cfg]
 sc = scene.dam_break(lat, h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
 n = len(sc["pos"])
@@ -32,7 +34,7 @@ while done < total:
     done += chunk
     st, fb = s.resort_stats()
     vmax = s.max_velocity()
-    row = dict(step=done, ms_per_step=round(ms, 3), neighbours_mean=round(s.get_stat(capi.STAT_HIT_MEAN), 2),
+    row = dict(step=done, t=round(done * dt, 4), ms_per_step=round(ms, 3), neighbours_mean=round(s.get_stat(capi.STAT_HIT_MEAN), 2),
                neighbours_max=s.get_stat(capi.STAT_HIT_MAX), overflow=s.get_stat(capi.STAT_HIT_OVERFLOW) / n,
                movers=round(s.get_stat(capi.STAT_MOVERS) / n, 4), full_sort_fallbacks_in_chunk=fb - fb0,
                vmax=round(vmax, 2), cells_per_step=round(vmax * dt / h, 3), cfl_dt_limit=round(0.4 * h / (cs + vmax), 6))
