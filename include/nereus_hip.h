@@ -204,8 +204,16 @@ uint64_t nrs_num_particles(nrs_ctx *ctx);
  * through nrs_get_params. */
 int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t nb, int update_grid);
 
-/* update() x nsteps with state resident on the device (no per-step PCIe traffic). Asynchronous:
- * returns after enqueueing; any nrs_download/nrs_get_array/nrs_synchronize waits for completion. */
+/* update() x nsteps with state resident on the device (no per-step PCIe traffic).  Asynchronous for the caller: a call with
+ * nsteps >= 2 hands the steps to a thread owned by the context and returns at once (before the device has finished, usually before
+ * it has started); nsteps <= 1 enqueues the step on the calling thread and returns without waiting for the device.  Every other
+ * nrs_* call on the context first waits until the queued steps have been enqueued, and nrs_synchronize / nrs_download /
+ * nrs_get_array additionally wait for the device.  A call the context's state does not allow (mid-update after nrs_step_partial, a
+ * host-driven IISPH step in progress) is refused at once with NRS_E_STATE; an error that a QUEUED step runs into is returned by the
+ * next call on the context, and the steps queued behind it are dropped.
+ * (Why a thread: the step loop reads one number back per step — the mover count that sizes the coherent re-sort's library calls, or
+ * the IISPH solver's exit test, sph_cuda.cu:736-741 — so whoever enqueues it runs about one step ahead of the device, not nsteps
+ * ahead.  NRS_FLAG_FULL_SORT SESPH contexts have no such read-back.) */
 int nrs_step(nrs_ctx *ctx, int nsteps);
 /* Test hook: run ONE update() but stop after `stop_stage` (NRS_STAGE_*), leaving the intermediate
  * arrays readable through nrs_get_array.  After a partial step the particle state is mid-update:

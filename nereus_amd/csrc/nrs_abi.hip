@@ -2,6 +2,10 @@
 // The contexts themselves are compiled per (precision, kernel set) in nrs_inst_*.hip.
 #include "nrs_ctx_base.h"
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 namespace nrs {
 
 thread_local std::string g_err;
@@ -22,11 +26,86 @@ static CtxBase *make_ctx(const nrs_config &c)
 
 using namespace nrs;
 
-struct nrs_ctx { CtxBase *impl; };
+// nrs_step is asynchronous for the CALLER: a call with two or more steps hands them to a thread the context owns and returns at
+// once (the step loop itself has to read one number back per step — the mover count that sizes the coherent re-sort's rocPRIM calls,
+// or the IISPH solver's density error — so the thread that enqueues it is never more than about a step ahead of the device; that
+// thread is the context's, not the caller's).  Every other entry point first waits until the queued steps have been enqueued
+// (drain) and reports the error a queued step ran into.  Single steps run on the calling thread: a caller that alternates
+// nrs_step(ctx, 1) with other calls (the slab exchange, a viewer that reads every frame) would only pay the hand-off.
+struct nrs_ctx {
+    CtxBase *impl = nullptr;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    int pending = 0;      // steps handed over, not yet taken by the worker
+    bool busy = false;    // the worker is inside impl->step
+    bool quit = false;
+    int err = NRS_OK;     // first error of a queued step, reported by the next call
+    std::string errMsg;
+
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return pending > 0 || quit; });
+            if (quit && pending == 0) return;
+            const int k = pending;
+            pending = 0;
+            busy = true;
+            lk.unlock();
+            int rc = NRS_OK;
+            if (hipSetDevice(impl->device) != hipSuccess) rc = fail(NRS_E_HIP, "hipSetDevice failed (step worker)");
+            else rc = impl->step(k, 0);
+            const std::string msg = rc != NRS_OK ? g_err : std::string();
+            lk.lock();
+            busy = false;
+            if (rc != NRS_OK && err == NRS_OK) { err = rc; errMsg = msg; pending = 0; } // (steps queued behind a failed one are dropped)
+            cv.notify_all();
+        }
+    }
+    // wait for the worker to go idle; returns (and clears) the error of a queued step
+    int drain()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return pending == 0 && !busy; });
+        const int rc = err;
+        if (rc != NRS_OK) { g_err = errMsg; err = NRS_OK; errMsg.clear(); }
+        return rc;
+    }
+    void wait_idle() // (for the entry points that cannot report an error: a queued step's error stays for the next call that can)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return pending == 0 && !busy; });
+    }
+    bool idle()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        return pending == 0 && !busy;
+    }
+    void submit(int k)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!worker.joinable()) worker = std::thread([this] { run(); });
+            pending += k;
+        }
+        cv.notify_all();
+    }
+    ~nrs_ctx()
+    {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(m); quit = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        delete impl;
+    }
+};
 
 #define CTX_GUARD(ctx)                                                   \
     if (!(ctx) || !(ctx)->impl) return fail(NRS_E_INVALID, "NULL context"); \
-    if (hipSetDevice((ctx)->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed")
+    if (hipSetDevice((ctx)->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed"); \
+    { const int drc_ = (ctx)->drain(); if (drc_ != NRS_OK) return drc_; }
 
 extern "C" {
 
@@ -68,14 +147,15 @@ int nrs_create(const nrs_config *cfg, const void *params, nrs_ctx **out)
     if (r != NRS_OK) { delete c; return r; }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { delete c; return fail(NRS_E_HIP, std::string("init sync: ") + hipGetErrorString(e)); }
-    *out = new nrs_ctx{c};
+    nrs_ctx *h = new nrs_ctx();
+    h->impl = c;
+    *out = h;
     return NRS_OK;
 }
 int nrs_destroy(nrs_ctx *ctx)
 {
     if (!ctx) return NRS_OK;
-    delete ctx->impl;
-    delete ctx;
+    delete ctx; // (joins the step worker, then deletes the context)
     return NRS_OK;
 }
 int nrs_set_params(nrs_ctx *ctx, const void *params)
@@ -100,7 +180,12 @@ int nrs_set_num_particles(nrs_ctx *ctx, uint64_t n)
     CTX_GUARD(ctx);
     return ctx->impl->set_n(n);
 }
-uint64_t nrs_num_particles(nrs_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->get_n() : 0; }
+uint64_t nrs_num_particles(nrs_ctx *ctx)
+{
+    if (!ctx || !ctx->impl) return 0;
+    ctx->wait_idle();
+    return ctx->impl->get_n();
+}
 int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t nb, int update_grid)
 {
     CTX_GUARD(ctx);
@@ -108,9 +193,18 @@ int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t 
 }
 int nrs_step(nrs_ctx *ctx, int nsteps)
 {
-    CTX_GUARD(ctx);
+    if (!ctx || !ctx->impl) return fail(NRS_E_INVALID, "NULL context");
     if (nsteps < 0) return fail(NRS_E_INVALID, "nsteps < 0");
-    return ctx->impl->step(nsteps, 0);
+    if (hipSetDevice(ctx->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed");
+    if (ctx->idle()) {
+        // nothing in flight: refuse a call the context's state does not allow NOW, as a synchronous call would (mid-update after a
+        // partial step, a host-driven IISPH step in progress, inconsistent state); single steps run right here
+        { const int drc = ctx->drain(); if (drc != NRS_OK) return drc; }
+        if (nsteps <= 1) return ctx->impl->step(nsteps, 0);
+        NRSCHK(ctx->impl->step(0, 0));
+    }
+    ctx->submit(nsteps); // (behind steps that are still being enqueued: their checks cover these too)
+    return NRS_OK;
 }
 int nrs_step_partial(nrs_ctx *ctx, int stop_stage)
 {
@@ -198,7 +292,12 @@ int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right,
     CTX_GUARD(ctx);
     return ctx->impl->slab_unpack(recv_left, recv_right, capacity);
 }
-uint64_t nrs_num_owned(nrs_ctx *ctx) { return (ctx && ctx->impl) ? ctx->impl->num_owned() : 0; }
+uint64_t nrs_num_owned(nrs_ctx *ctx)
+{
+    if (!ctx || !ctx->impl) return 0;
+    ctx->wait_idle();
+    return ctx->impl->num_owned();
+}
 int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts)
 {
     CTX_GUARD(ctx);

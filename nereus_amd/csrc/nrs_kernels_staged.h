@@ -339,6 +339,11 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
             }
             dens[i] = d;
             if (pres) pres[i] = pr;
+            if (SHARE && !FAST && hb.pairs && active) { // what the list-driven force kernel gathers (HitBuffer::pairs, k_density_tiled)
+                PrePair<R> q;
+                q.prq = pr / (d * d); q.mrho = P.particleMass / d;
+                reinterpret_cast<PrePair<R> *>(hb.pairs)[i] = q;
+            }
             if (FAST && fq) {
                 const float inv = active ? 1.0f / d : 0.f;
                 FastPair z; z.pr = pr * inv * inv; z.invRho = inv;
@@ -373,6 +378,11 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
     }
     dens[i] = d;
     if (pres) pres[i] = pr;
+    if (SHARE && !FAST && hb.pairs) { // (p / rho^2, m / rho) with the operands and IEEE divisions of the force loop, as k_density_tiled leaves
+        PrePair<float> q;             // them: round 2 made the list-driven force kernel gather these, and this launch did not write them —
+        q.prq = pr / (d * d); q.mrho = P.particleMass / d; // found by the first test that ran the staged launch (round 3)
+        reinterpret_cast<PrePair<float> *>(hb.pairs)[i] = q;
+    }
     if (FAST && fq) {
         const float inv = 1.0f / d;
         FastPair z; z.pr = pr * inv * inv; z.invRho = inv;

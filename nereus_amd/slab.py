@@ -332,13 +332,42 @@ def rank_scene(lattice_per_rank, rank, world, params, real=np.float32, spacing=0
     return p, cuts, pos, vel, bi, vb.astype(real), dict(particles=gnx * ny * nz, tank=(tx, ty, tz))
 
 
-def capacities(lattice, h, n_owned, real=np.float32):
+def write_rank_scene(path, params, cell_lo, cell_hi, halo, msg_capacity, ctx_capacity, pos, vel, bi, vbi, iisph=False):
+    """One rank's input for the C++ driver of the exchange (nereus_amd/host/tools/slab_rccl.cpp; fp32): header, parameter block,
+    particles, boundary particles."""
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 4)
+    vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 4)
+    nb = 0 if bi is None else len(bi)
+    p = np.array(params).reshape(1).copy()
+    with open(path, "wb") as f:
+        f.write(np.array([0x4C53524E, len(pos), nb], np.uint32).tobytes())
+        f.write(np.array([max(cell_lo, -(1 << 30)), min(cell_hi, 1 << 30), halo], np.int32).tobytes())
+        f.write(np.array([msg_capacity, ctx_capacity, 1 if iisph else 0, p.nbytes], np.uint32).tobytes())
+        f.write(p.tobytes())
+        f.write(pos.tobytes())
+        f.write(vel.tobytes())
+        if nb:
+            f.write(np.ascontiguousarray(bi, np.float32).tobytes())
+            f.write(np.ascontiguousarray(vbi, np.float32).tobytes())
+
+
+def read_rank_result(path):
+    """(pos, vel, truncated_steps, last_iterations) written by slab_rccl"""
+    raw = open(path, "rb").read()
+    n, trunc, iters, _ = np.frombuffer(raw[:16], np.uint32)
+    a = np.frombuffer(raw[16:], np.float32).reshape(2, int(n), 4)
+    return a[0].copy(), a[1].copy(), int(trunc), int(iters)
+
+
+def capacities(lattice, h, n_owned, real=np.float32, headroom=1.6):
     """(message capacity, context capacity) in particles for a slab of the lattice scene: a 2-cell halo holds
-    about HALO_CELLS * ny * nz * (h/d) lattice particles; 60 % head-room for compression plus migrants."""
+    about HALO_CELLS * ny * nz * (h/d) lattice particles; 60 % head-room for compression plus migrants (a run that
+    lets the column settle and the dam break — bench.py's spin-up — asks for more: the fluid at the foot of the
+    8.8 m column ends up almost twice as dense as the lattice)."""
     nx, ny, nz = lattice
     d = float(real(h)) - 0.005
     halo_est = int(HALO_CELLS * ny * nz * (h / d))
-    msg_cap = int(1.6 * halo_est) + 8192
+    msg_cap = int(headroom * halo_est) + 8192
     return msg_cap, int(n_owned * 1.15) + 4 * msg_cap
 
 
@@ -366,11 +395,19 @@ def bench_main(args, lattice, rank, world, local_rank):
     max_iters = int(getattr(args, "iisph_max_iters", 2) or 2)
     halo = iisph_halo_cells(max_iters) if iisph else HALO_CELLS
     params = default_params(1 if iisph else 0)
+    from bench import DEFAULT_DT, DEFAULT_SPIN_UP
+
+    # the same window as the one-GPU line: untimed spin-up to the broken dam under a CFL-respecting time step (bench.py)
+    spin_up = args.spin_up if getattr(args, "spin_up", None) is not None else (0 if iisph else DEFAULT_SPIN_UP)
+    if getattr(args, "dt", None) is not None or not iisph:
+        params["timestep"][0] = args.dt if getattr(args, "dt", None) is not None else DEFAULT_DT
     t_gen = time.perf_counter()
     p, cuts, pos, vel, bi, vbi, info = rank_scene(lattice, rank, world, params)
     t_gen = time.perf_counter() - t_gen
     nx, ny, nz = lattice
-    msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos))
+    msg_cap, cap = capacities(lattice, float(p["interactionRadius"][0]), len(pos), headroom=3.0 if spin_up else 1.6)
+    if spin_up:
+        cap += len(pos) // 4   # (count-balanced re-cuts keep the owned share near N / world; room for the drift between two re-cuts)
     if iisph:  # wider halo (8 cells instead of 2 for two iterations): halo / 2 times the halo particles per message
         msg_cap, cap = (halo // HALO_CELLS) * msg_cap, cap + (halo - HALO_CELLS) * msg_cap
     eng = HipSlabEngine(p, cap, msg_cap, cuts[rank], cuts[rank + 1], local_rank, halo=halo, iisph=iisph)
@@ -378,8 +415,28 @@ def bench_main(args, lattice, rank, world, local_rank):
     drv = SlabDriver(eng, rank, world, stage_through_host=(backend != "nccl"))
     n_global = info["particles"]
 
+    # NEREUS_BENCH_REBALANCE=K: count-balanced re-cut every K steps (default: every 50 steps of a run with a spin-up — the dam
+    # flows along x, fixed cuts would drift out of balance and out of the message capacity; off in a run that times the resting
+    # column, where the cuts have nothing to follow and the re-cut costs a histogram + an all-reduce)
+    rebalance_every = int(os.environ.get("NEREUS_BENCH_REBALANCE", "50" if spin_up else "0"))
+    grid_x = int(p["gridSize"][0][0])
+    steps_done = 0
+
+    def run(k):
+        nonlocal steps_done
+        for _ in range(k):
+            if rebalance_every and world > 1 and steps_done and steps_done % rebalance_every == 0:
+                drv.rebalance(grid_x, msg_cap // 4)
+            drv.exchange()
+            if iisph:
+                drv.iisph_step()
+            else:
+                eng.step(1)
+            steps_done += 1
+
+    run(spin_up)
     eng.solver.set_profiling(True)
-    drv.step(args.warmup)
+    run(args.warmup)
     if args.warmup == 0:
         drv.exchange()  # untimed: creates the communicators (a partition without a step changes no particle)
     eng.synchronize()
@@ -391,18 +448,7 @@ def bench_main(args, lattice, rank, world, local_rank):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # NEREUS_BENCH_REBALANCE=K: count-balanced re-cut every K steps inside the timed region (off by default: in a 100-step window
-    # that starts from the resting column the cuts have nothing to follow yet, and the re-cut costs a histogram + an all-reduce)
-    rebalance_every = int(os.environ.get("NEREUS_BENCH_REBALANCE", "0"))
-    grid_x = int(p["gridSize"][0][0])
-    for it in range(args.steps):
-        if rebalance_every and it and it % rebalance_every == 0:
-            drv.rebalance(grid_x, msg_cap // 4)
-        drv.exchange()
-        if iisph:
-            drv.iisph_step()
-        else:
-            eng.step(1)
+    run(args.steps)
     eng.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
@@ -413,6 +459,10 @@ def bench_main(args, lattice, rank, world, local_rank):
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    vm = torch.tensor([eng.solver.max_velocity()], dtype=torch.float64, device=dev)   # CFL check of the window's end state
+    dist.all_reduce(vm, op=dist.ReduceOp.MAX)
+    vmax = float(vm.item())
+    h_, dt_, cs_ = float(p["interactionRadius"][0]), float(p["timestep"][0]), float(p["soundSpeed"][0])
     drv.finish()
     owned = torch.tensor([eng.n_owned], dtype=torch.int64, device=dev)
     dist.all_reduce(owned, op=dist.ReduceOp.SUM)
@@ -461,6 +511,10 @@ def bench_main(args, lattice, rank, world, local_rank):
             "particles": n_global,
             "num_cells": num_cells,
             "steps_per_s": args.steps / dt,
+            "spin_up_steps": spin_up,
+            "first_timed_step": spin_up + args.warmup,
+            "dt": float(p["timestep"][0]),
+            "rebalance_every": rebalance_every,
             "parallelism": "slab x%d" % world,
             "message_bytes_per_direction": eng.msg_bytes,
             "sort": dict(zip(("coherent_resort_steps", "fell_back_to_full_sort"), eng.solver.resort_stats())),
@@ -475,6 +529,8 @@ def bench_main(args, lattice, rank, world, local_rank):
                            "achieved_per_gpu": bpp * value / world / 1e9, "frac_per_gpu": bpp * value / world / 1e9 / HBM_PEAK_GBS},
         },
         "scene_build_s": t_gen,
+        "developed": {"first_step": spin_up + args.warmup, "steps": args.steps, "vmax": vmax, "cfl_dt_limit": 0.4 * h_ / (cs_ + vmax), "dt": dt_},
+        "cfl_ok": bool(0.4 * h_ / (cs_ + vmax) >= dt_),
     }
     dist.destroy_process_group()
     return out

@@ -50,10 +50,12 @@ def test_bench_line_two_ranks_one_gpu_gloo(hip_lib):
     env = dict(os.environ, NEREUS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "48,40,40", "--steps", "4",
-                        "--warmup", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--warmup", "2", "--spin-up", "120"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_line(r.stdout)
     for k in KEYS + ("backend",):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["backend"].startswith("gloo")
     assert d["config"]["particles"] == 2 * 48 * 40 * 40
+    # the same window rule as the one-GPU line: spin-up (with count-balanced re-cuts every 50 steps) under the CFL-stable dt
+    assert d["config"]["spin_up_steps"] == 120 and d["config"]["rebalance_every"] == 50 and d["cfl_ok"] is True

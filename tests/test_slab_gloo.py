@@ -403,3 +403,55 @@ def test_iisph_slabs_iteration_cap_is_reported_not_fatal(tmp_path, hip_lib):
     every rank and counted — the run goes on, the contexts are not left mid-step — and equals the single domain capped alike."""
     _check_order_independent(4, True, tmp_path, force_iters=4, halo=8, single_iters=2)
     assert _run_iisph.truncated == [4, 4]
+
+
+# ---------------------------------------------------------------- the exchange driven from C++ over RCCL
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["sesph", "iisph"])
+def test_slab_rccl_cpp_driver_one_rank(tmp_path, hip_lib, solver):
+    """nereus_amd/host/tools/slab_rccl.cpp (RCCL send/recv + all-reduce on the context's stream, no interpreter in the loop), as far as a
+    one-GPU box can run it: RCCL refuses two ranks on one device (tools/probe_rccl_same_gpu.py), so ONE rank — communicator
+    bootstrap through the id file, the pack / (no neighbour) / unpack bracket every step, for IISPH the all-reduced exit test — against
+    a single-domain context of the same scene.  With more ranks the same binary exchanges over xGMI; that path has never run."""
+    import subprocess
+
+    sys.path.insert(0, ROOT)
+    from nereus_amd import capi, slab
+    from nereus_amd.params import default_params
+    from tests.common import rel_err
+
+    exe = os.path.join(ROOT, "nereus_amd", "nereus_slab_rccl")
+    assert os.path.exists(exe), "build it: make -C nereus_amd/host"
+    iisph = solver == "iisph"
+    if iisph:
+        p, pos, vel = _iisph_scene()
+        bi = vbi = None
+        halo, steps = 8, 4
+    else:
+        p, cuts, pos, vel, bi, vbi, info = slab.rank_scene((24, 20, 18), 0, 1, default_params(0))
+        halo, steps = 2, 12
+    ids = np.arange(len(pos), dtype=np.float32)
+    if not iisph:
+        vel = vel.copy(); vel[:, 3] = ids
+    scene_file, out_file = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    slab.write_rank_scene(scene_file, p, slab.NO_CUT_LO, slab.NO_CUT_HI, halo, 8192, 4 * len(pos), pos, vel, bi, vbi, iisph=iisph)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", NEREUS_NCCL_ID_FILE=str(tmp_path / "nccl.id"),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, scene_file, str(steps), out_file], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    gp, gv, trunc, iters = slab.read_rank_result(out_file)
+    assert len(gp) == len(pos) and trunc == 0
+    s = capi.Solver(p, len(pos), solver=capi.IISPH if iisph else capi.SESPH, flags=capi.FLAG_IISPH_SELF_BY_SLOT if iisph else 0)
+    s.set_particles(pos, vel)
+    s.set_boundaries(bi, vbi, update_grid=False)
+    s.step(steps)
+    rp, rv = s.download()
+    if iisph:
+        assert iters == s.last_iterations
+        d, idx = _match(rp, gp)
+        assert len(np.unique(idx)) == len(gp) and d.max() < 1e-5
+        assert rel_err(gv[:, :3], rv[idx, :3]) <= 1e-4
+    else:
+        a, b = np.argsort(gv[:, 3], kind="stable"), np.argsort(rv[:, 3], kind="stable")
+        assert np.array_equal(gv[a, 3], ids)
+        assert rel_err(gp[a, :3], rp[b, :3]) <= 1e-5 and rel_err(gv[a, :3], rv[b, :3]) <= 1e-5

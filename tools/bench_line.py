@@ -5,3 +5,9 @@ print("ms/step", round(d["ms_per_step"], 4), "value %.4g" % d["value"], {k: roun
 dev = d.get("developed")
 if dev:
     print("developed", round(dev["ms_per_step"], 4), {k: round(v, 4) for k, v in dev["stage_ms"].items()}, "overflow", dev.get("hit_list_overflow_fraction"))
+for k in ("resting",):
+    r = d.get(k)
+    if r:
+        print(k, round(r["ms_per_step"], 4), {a: round(b, 4) for a, b in r["stage_ms"].items()})
+print("cfl_ok", d.get("cfl_ok"), "spin_up", d["config"].get("spin_up_steps"), "dt", d["config"].get("dt"), "roofline frac", round(d["roofline"]["frac"], 4),
+      "whole-step frac", round(d["roofline"]["whole_step"]["frac"], 4))

@@ -63,7 +63,8 @@ def main():
     with `tail steps` the statistics cover only the last so-many steps of the traced run (developed-flow profiles)"""
     src, name, workload, particles = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     tail = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    root = os.environ.get("NEREUS_PROFILE_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(root, exist_ok=True)
     if tail:
         tail_stats(os.path.join(src, "trace", "t_kernel_trace.csv"), os.path.join(root, name + "_kernel_stats.csv"), tail)
     else:
