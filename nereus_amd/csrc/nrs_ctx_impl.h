@@ -246,6 +246,18 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slotOrderValid) return AS_SLOT_ORDER;
         return AS_FRESH;
     }
+    // Transitions.  Every write to the coupled fields above goes through one of these (round 3: the fields used to be set one by one
+    // at ~30 places, which is how a count could be reset before it was read); array_state() reads the result back as ONE state.
+    void drop_prepared_keys() { hashReady = false; rsPending = false; rsCountKnown = false; }   // the keys were consumed, or are void
+    void to_fresh() { drop_prepared_keys(); slotOrderValid = false; classifiedValid = false; } // -> AS_FRESH: compact arrays, any order
+    void keys_ready(uint32_t *h, uint32_t *i) { hashNext = h; indexNext = i; hashReady = true; } // -> AS_KEYS_READY
+    void split_queued() { rsPending = true; }                                                    // -> AS_SPLIT_QUEUED, count still on the device
+    void split_queued_known(uint32_t movers) { rsPending = true; rsCountKnown = true; rsKnownCount = movers; } // ..., count on the host
+    void to_holes(uint32_t extent, uint32_t movers)                                             // -> AS_HOLES (in-place slab partition)
+    {
+        holesPending = true; physN = extent; packedHashValid = true; hashReady = true;
+        split_queued_known(movers);
+    }
     int validate(const char *where) const
     {
         if (array_state() != AS_INVALID) return NRS_OK;
@@ -422,7 +434,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     int invalidate_grid_state()
     {
         NRSCHK(compact_holes());
-        hashReady = false; rsPending = false; rsCountKnown = false; slotOrderValid = false; classifiedValid = false;
+        to_fresh();
         packedHashValid = false; cellsClean = false;
         return NRS_OK;
     }
@@ -450,8 +462,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slabOn) nOwned = n; // (until the next partition says otherwise)
         midStep = false;
         iisphPhase = 0; iisphIter = 0; // new particles abandon a host-driven IISPH step that was in progress
-        hashReady = false; rsPending = false; rsCountKnown = false;
-        slotOrderValid = false; classifiedValid = false;
+        to_fresh();
         return NRS_OK;
     }
     int set_n(uint64_t nn) override
@@ -459,7 +470,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(validate("nrs_set_num_particles"));
         if (nn > cap) return fail(NRS_E_CAPACITY, "n exceeds capacity");
         NRSCHK(compact_holes());
-        if (nn != n) { hashReady = false; rsPending = false; rsCountKnown = false; slotOrderValid = false; classifiedValid = false; }
+        if (nn != n) to_fresh();
         if (nn != n) { iisphPhase = 0; iisphIter = 0; } // (the hit lists of a predicted step belong to the old particle set)
         n = nn;
         if (slabOn) nOwned = n;
@@ -668,9 +679,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         }
         const bool resort = hashReady && rsPending && stop != NRS_STAGE_HASH && stop != NRS_STAGE_SORT;
         const bool countKnown = rsCountKnown; // (slab runs: the host already has the mover count)
-        hashReady = false;
-        rsPending = false;
-        rsCountKnown = false;
+        drop_prepared_keys(); // (consumed by this step)
         hashCur = kIn; indexCur = vIn;
         if (stop == NRS_STAGE_HASH) return NRS_OK;
 
@@ -764,7 +773,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (!holesPending) return NRS_OK;
         holesPending = false;
         const uint32_t NP = physN, nTiles = nblocks(NP);
-        hashReady = false; rsPending = false; rsCountKnown = false; packedHashValid = false;
+        drop_prepared_keys(); packedHashValid = false;
         if (!NP) return NRS_OK;
         NRSCHK(clean_tile_counts());
         hipLaunchKernelGGL(k_holes_count, dim3(nTiles), dim3(BLOCK), 0, stream, hashNext, rsTileDead.as<uint32_t>(), NP);
@@ -791,7 +800,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(), offsets_movers(),
                            rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, clear ? cellStart.as<uint32_t>() : (uint32_t *)nullptr);
         splitClearedCells = clear;
-        rsPending = true;
+        split_queued();
         NRSCHK(ev_end());
         return NRS_OK;
     }
@@ -875,8 +884,8 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 launch_forces_tiled<R, KSET, SURF, HAS_B>(stream, P, G, share ? &hb : (const HitBuffer *)nullptr, posB.as<T4>(),
                                                           velB.as<T4>(), dens.as<R>(), presB.as<R>(), (T4 *)nullptr, &fo, N,
                                                           (HAS_B && share && wallsDeferred) ? &wv : (const WallList *)nullptr);
-            hashNext = fo.hash; indexNext = fo.index;
-            hashReady = !slabOn; // a slab run re-partitions the arrays before the next step
+            if (!slabOn) keys_ready(fo.hash, fo.index);
+            else { hashNext = fo.hash; indexNext = fo.index; } // a slab run re-partitions the arrays before the next step (AS_SLOT_ORDER)
             fusedThisStep = true;
             if (resort) {
                 NRSCHK(ev_end());
@@ -1030,8 +1039,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                            resort ? rsTileMovers.as<uint32_t>() : (uint32_t *)nullptr, slabOn ? 1 : 0);
         NRSCHK(ev_end());
         if (keys) {
-            hashNext = nh; indexNext = ni;
-            hashReady = true;
+            keys_ready(nh, ni);
             if (resort) NRSCHK(queue_resort_split(N));
         }
         return NRS_OK;
@@ -1344,25 +1352,17 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             return fail(NRS_E_HIP, "inconsistent slab stream totals");
         const bool overflow = (uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > mcap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > mcap ||
                               tot[ST_GHOST] > mcap;
-        hashReady = false;
-        rsPending = false;
-        rsCountKnown = false;
-        slotOrderValid = false;
+        to_fresh();
         if (inplace) {
-            holesPending = true;
-            physN = N;
-            packedHashValid = true; // hashNext / indexNext hold key and slot of every live slot, 0xffffffff marks the dead ones
-            rsPending = true;
-            rsCountKnown = true;
-            rsKnownCount = tot[ST_CHANGED]; // arrivals are added by nrs_slab_unpack
-            hashReady = true;
+            // hashNext / indexNext hold key and slot of every live slot, 0xffffffff marks the dead ones; arrivals are added to the mover
+            // count by nrs_slab_unpack
+            to_holes(N, tot[ST_CHANGED]);
         } else {
             if (N) { std::swap(posA.p, posB.p); std::swap(velA.p, velB.p); }
             else { packKeys = hashA.as<uint32_t>(); packVals = indexA.as<uint32_t>(); packResort = false; }
             packedHashValid = N != 0; // k_slab_scatter hashed the particles that stay (with the current parameters)
         }
         packInplace = inplace;
-        classifiedValid = false;
         n = tot[ST_STAY];
         nOwned = n;
         ghostCount = tot[ST_GHOST];
@@ -1425,9 +1425,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(launch_resort_scan(nTiles, false));
             hipLaunchKernelGGL((k_resort_split<false>), dim3(nTiles), dim3(BLOCK), 0, stream, rsPrevPacked.as<uint32_t>(), hashNext,
                                offsets_movers(), offsets_movers(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
-            rsPending = true;
-            rsCountKnown = true; // everything appended is a mover, and the partition counted the cell changers
-            rsKnownCount = packChanged + A.start[5];
+            split_queued_known(packChanged + A.start[5]); // everything appended is a mover, and the partition counted the cell changers
             rsTilesDirty = false; // the scan resets the counts it reads
         }
         packResort = false;

@@ -166,9 +166,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void
                         const uint32_t e = G.cellEnd[h];
                         for (uint32_t j = s; j < e; ++j) {
                             if (j == i) continue;
-                            const V3<R> v1v2 = velAdv1 - xyz<R>(I.velAdv[j]);
+                            const V3<R> vij = velAdv1 - xyz<R>(I.velAdv[j]);
                             const V3<R> d = pos1 - xyz<R>(sPos[j]);
-                            if (length(d) < ir) res += (dt * pm * dot(v1v2, W_grad<R, KSET>(d, ir, kpg)));
+                            if (length(d) < ir) res += (dt * pm * dot(vij, W_grad<R, KSET>(d, ir, kpg)));
                         }
                     }
                     rho_advf += res;
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void
                 const R psi = (rd * b.w);
                 part += (dt * psi * dot(vel1, W_grad<R, KSET>(d, ir, kpg)));
             } else if (j != i) {
-                const V3<R> v1v2 = velAdv1 - xyz<R>(I.velAdv[j]);
+                const V3<R> vij = velAdv1 - xyz<R>(I.velAdv[j]);
                 const V3<R> d = pos1 - xyz<R>(sPos[j]);
-                if (length(d) < ir) part += (dt * pm * dot(v1v2, W_grad<R, KSET>(d, ir, kpg)));
+                if (length(d) < ir) part += (dt * pm * dot(vij, W_grad<R, KSET>(d, ir, kpg)));
             }
         });
         if (partB) rho_advb += part; else rho_advf += part;
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
     const R omega = (R)0.5;
     R rho_corr = rho_adv + fsum + bsum;
     const R dt2 = dt * dt;
-    const R denom = aii * dt2;
+    const R diagDt2 = aii * dt2;
     const R b = rd - rho_adv;
-    if (fabs(denom) > 1.1920928955078125e-07f /* FLT_EPSILON */)
-        p_l = (R)((1.0 - omega) * previous_p_l + (omega / denom) * (b - dt2 * (bsum + fsum)));
+    if (fabs(diagDt2) > 1.1920928955078125e-07f /* FLT_EPSILON */)
+        p_l = (R)((1.0 - omega) * previous_p_l + (omega / diagDt2) * (b - dt2 * (bsum + fsum)));
     else
         p_l = (R)0.0;
     watch_finite<R>(I.nonFinite, p_l); // (before the clamp, which would hide a NaN)

@@ -8,7 +8,7 @@
 //
 // What each kernel computes is specified by the reference kernel cited above it.  The physics statements of the force /
 // density / IISPH loops (and the smoothing kernels of nrs_math.h) are restatements of the reference's expressions IN THE
-// REFERENCE'S EVALUATION ORDER, with its operand names where that helps checking them line by line: the parity goal
+// REFERENCE'S EVALUATION ORDER (the local names are this build's own; the oracle keeps the reference's for line-by-line reading): the parity goal
 // (every float sum bit-identical to the reference's arithmetic) forces the expression order; everything around them —
 // thread mapping, memory layout, templates, boundary packing, double-buffered P_l — is this build's own.
 #pragma once
@@ -248,38 +248,38 @@ NRS_DEV void cell_forces(const Params<R> &P, const GridView<R> &G, ForceAcc<R> &
         const uint32_t e = G.cellEnd[h];
         for (uint32_t j = s; j < e; ++j) {
             if (j == self) continue;
-            const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
-            if (length(p1p2) < ir) {
-                const R dens2 = sDens[j];
-                const R pres2 = sPres[j];
+            const V3<R> rij = pos1 - xyz<R>(sPos[j]);
+            if (length(rij) < ir) {
+                const R rhoNb = sDens[j];
+                const R pNb = sPres[j];
                 const V3<R> vel2 = xyz<R>(sVel[j]);
                 const R diameter = (R)(2.0 * P.particleRadius);
                 const R diameter2 = diameter * diameter;
-                const V3<R> v1v2 = vel1 - vel2;
-                const R d1sq = dens * dens;
-                const R d2sq = dens2 * dens2;
-                V3<R> kpressure_grad, kvisco_grad;
-                R kernel, kernel_diameter;
+                const V3<R> vij = vel1 - vel2;
+                const R rhoSqOwn = dens * dens;
+                const R rhoSqNb = rhoNb * rhoNb;
+                V3<R> gradSpiky, gradVisc;
+                R kernel, wAtDiameter;
                 if (KSET == KS_MONAGHAN) {
-                    kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
-                    kvisco_grad = kpressure_grad;
-                    kernel = Wmonaghan<R>(p1p2, ir);
-                    kernel_diameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
+                    gradSpiky = Wmonaghan_grad<R>(rij, ir);
+                    gradVisc = gradSpiky;
+                    kernel = Wmonaghan<R>(rij, ir);
+                    wAtDiameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
                 } else {
-                    kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
-                    kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
-                    kernel = Wdefault<R>(p1p2, ir, kp);
-                    kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
+                    gradSpiky = Wpressure_grad<R>(rij, ir, kprg);
+                    gradVisc = Wviscosity_grad<R>(rij, ir, kvg, kvd);
+                    kernel = Wdefault<R>(rij, ir, kp);
+                    wAtDiameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
                 }
-                A.fpres = A.fpres + (m2 * (pres / d1sq + pres2 / d2sq) * kpressure_grad);
-                const R a = dot(p1p2, kvisco_grad);
-                const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
-                A.fvisc = A.fvisc + (m2 / dens2 * v1v2 * (a / b));
+                A.fpres = A.fpres + (m2 * (pres / rhoSqOwn + pNb / rhoSqNb) * gradSpiky);
+                const R a = dot(rij, gradVisc);
+                const R b = dot(rij, rij) + 0.01f * (ir * ir);
+                A.fvisc = A.fvisc + (m2 / rhoNb * vij * (a / b));
                 if (SURF) {
                     V3<R> ai = mk3<R>(0, 0, 0);
-                    const R r2 = dot(p1p2, p1p2);
-                    if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
-                    else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+                    const R r2 = dot(rij, rij);
+                    if (r2 > diameter2) ai = ai - (kappa / pm * pm * rij * kernel);
+                    else ai = ai - (kappa / pm * pm * rij * wAtDiameter);
                     A.fsurf = A.fsurf + ai;
                 }
             }
@@ -297,24 +297,24 @@ NRS_DEV void cell_forces(const Params<R> &P, const GridView<R> &G, ForceAcc<R> &
                 const R vbi = bq.w;
                 const V3<R> vpos = xyz<R>(bq);
                 const R psi = (rd * vbi);
-                const V3<R> p1p2 = pos1 - vpos;
-                const V3<R> v1v2 = vel1;
+                const V3<R> rij = pos1 - vpos;
+                const V3<R> vij = vel1;
                 R kernel;
                 V3<R> grad;
                 if (KSET == KS_MONAGHAN) {
-                    kernel = Wmonaghan<R>(p1p2, ir);
-                    grad = Wmonaghan_grad<R>(p1p2, ir);
+                    kernel = Wmonaghan<R>(rij, ir);
+                    grad = Wmonaghan_grad<R>(rij, ir);
                 } else {
-                    kernel = Wdefault<R>(p1p2, ir, P.kpoly);
-                    grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+                    kernel = Wdefault<R>(rij, ir, P.kpoly);
+                    grad = Wdefault_grad<R>(rij, ir, P.kpoly_grad);
                 }
-                A.fbound = A.fbound + (beta * psi * p1p2 * kernel);
+                A.fbound = A.fbound + (beta * psi * rij * kernel);
                 A.fpres = A.fpres + (-pm * psi * (pres / (dens * dens)) * grad);
-                const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
-                const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
-                const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
-                const R Pij = -nu * (nom / denom);
-                A.fvisc = A.fvisc - (pm * psi * Pij * grad);
+                const R nuWall = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
+                const R approach = (R)fmax((double)dot(vij, rij), 0.0);
+                const R normSq = dot(rij / length(rij), rij / length(rij)) + epsilon * ir * ir;
+                const R friction = -nuWall * (approach / normSq);
+                A.fvisc = A.fvisc - (pm * psi * friction * grad);
             }
         }
     }
@@ -540,11 +540,11 @@ __global__ __launch_bounds__(BLOCK) void k_advection_ref(Params<R> P, GridView<R
                         for (uint32_t j = s; j < e; ++j) {
                             if (j == i) continue;
                             const V3<R> velAdv2 = xyz<R>(I.velAdv[j]);
-                            const V3<R> v1v2 = velAdv1 - velAdv2;
+                            const V3<R> vij = velAdv1 - velAdv2;
                             const V3<R> d = pos1 - xyz<R>(sPos[j]);
                             if (length(d) < ir) {
                                 const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
-                                res += (dt * pm * dot(v1v2, grad));
+                                res += (dt * pm * dot(vij, grad));
                             }
                         }
                     }
@@ -558,10 +558,10 @@ __global__ __launch_bounds__(BLOCK) void k_advection_ref(Params<R> P, GridView<R
                         for (uint32_t j = s; j < e; ++j) { // no cut-off: relies on W_grad == 0 beyond h (Q8)
                             const typename Vec4T<R>::type b = G.sB[j];
                             const V3<R> d = pos1 - xyz<R>(b);
-                            const V3<R> v1v2 = vel1;
+                            const V3<R> vij = vel1;
                             const R psi = (rd * b.w);
                             const V3<R> grad = W_grad<R, KSET>(d, ir, kpg);
-                            res += (dt * psi * dot(v1v2, grad));
+                            res += (dt * psi * dot(vij, grad));
                         }
                     }
                     rho_advb += res;
@@ -714,10 +714,10 @@ __global__ __launch_bounds__(BLOCK) void k_pressure_ref(Params<R> P, GridView<R>
     const R omega = (R)0.5;
     R rho_corr = rho_adv + fsum + bsum;
     const R dt2 = dt * dt;
-    const R denom = aii * dt2;
+    const R diagDt2 = aii * dt2;
     const R b = rd - rho_adv;
-    if (fabs(denom) > 1.1920928955078125e-07f /* FLT_EPSILON */)
-        p_l = (R)((1.0 - omega) * previous_p_l + (omega / denom) * (b - dt2 * (bsum + fsum)));
+    if (fabs(diagDt2) > 1.1920928955078125e-07f /* FLT_EPSILON */)
+        p_l = (R)((1.0 - omega) * previous_p_l + (omega / diagDt2) * (b - dt2 * (bsum + fsum)));
     else
         p_l = (R)0.0;
     const R p = (R)fmax((double)p_l, 0.0);

@@ -430,7 +430,7 @@ NRS_DEV ForceAcc<float> forces_from_hits_fast(const Params<float> &P, const Grid
     const float eps = 0.01f * h2;
     const float diameter = 2.0f * P.particleRadius, diameter2 = diameter * diameter;
     const float td = fmaxf(h2 - diameter2, 0.f);
-    const float kernel_diameter = P.kpoly * td * td * td;
+    const float wAtDiameter = P.kpoly * td * td * td;
     const float ks = P.surfaceTension / P.particleMass * P.particleMass; // the reference's `kappa / m * m`
     // fluid hits, FORCE_BATCH at a time: the list entries of a batch are requested together, then the three gathers of
     // every pair of the batch (memory-level parallelism: the walk is bound by the latency of dependent gathers — one
@@ -462,7 +462,7 @@ NRS_DEV ForceAcc<float> forces_from_hits_fast(const Params<float> &P, const Grid
             A.fvisc.z = __builtin_fmaf(cv, vel1.z - vj[u].z, A.fvisc.z);
             if (SURF) {
                 const float t = fmaxf(h2 - d2, 0.f);
-                const float kern = (d2 > diameter2) ? P.kpoly * (t * t * t) : kernel_diameter;
+                const float kern = (d2 > diameter2) ? P.kpoly * (t * t * t) : wAtDiameter;
                 const float cs = on ? -ks * kern : 0.f;
                 A.fsurf.x = __builtin_fmaf(cs, rx, A.fsurf.x); A.fsurf.y = __builtin_fmaf(cs, ry, A.fsurf.y); A.fsurf.z = __builtin_fmaf(cs, rz, A.fsurf.z);
             }
@@ -485,10 +485,10 @@ NRS_DEV V3<float> boundary_pair_force_fast(const Params<float> &P, FastPair own,
     const float g = P.kpoly_grad * (t * t); // gradW_poly6 = g * r
     const float cb = P.beta * psi * kern;
     const float cp = -m * psi * own.pr * g;
-    const float nu = (P.viscosity * h * P.soundSpeed) * (own.invRho * own.invRho);
-    const float nom = fmaxf(__builtin_fmaf(vel1.z, rz, __builtin_fmaf(vel1.y, ry, vel1.x * rx)), 0.f);
-    const float Pij = -nu * nom * (1.0f / (1.0f + 0.01f * h * h)); // |r/|r||^2 + eps h^2 in the denominator
-    const float cv = -(m * psi * Pij * g);
+    const float nuWall = (P.viscosity * h * P.soundSpeed) * (own.invRho * own.invRho);
+    const float approach = fmaxf(__builtin_fmaf(vel1.z, rz, __builtin_fmaf(vel1.y, ry, vel1.x * rx)), 0.f);
+    const float friction = -nuWall * approach * (1.0f / (1.0f + 0.01f * h * h)); // |r/|r||^2 + eps h^2 in the denominator
+    const float cv = -(m * psi * friction * g);
     const float k = cb - m * cp + (2.0f * m * P.viscosity) * cv;
     return mk3<float>(k * rx, k * ry, k * rz);
 }

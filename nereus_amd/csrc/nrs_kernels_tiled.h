@@ -545,25 +545,25 @@ NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3
     const R epsilon = (R)0.01;
     const R beta = P.beta, rd = P.restDensity;
     const R psi = (rd * bq.w);
-    const V3<R> p1p2 = pos1 - xyz<R>(bq);
-    const V3<R> v1v2 = vel1;
+    const V3<R> rij = pos1 - xyz<R>(bq);
+    const V3<R> vij = vel1;
     R kernel;
     V3<R> grad;
     if (KSET == KS_MONAGHAN) {
-        kernel = Wmonaghan<R>(p1p2, ir);
-        grad = Wmonaghan_grad<R>(p1p2, ir);
+        kernel = Wmonaghan<R>(rij, ir);
+        grad = Wmonaghan_grad<R>(rij, ir);
     } else {
-        kernel = Wdefault<R>(p1p2, ir, P.kpoly);
-        grad = Wdefault_grad<R>(p1p2, ir, P.kpoly_grad);
+        kernel = Wdefault<R>(rij, ir, P.kpoly);
+        grad = Wdefault_grad<R>(rij, ir, P.kpoly_grad);
     }
     BoundaryTerms<R, KSET> T;
-    T.bound = (beta * psi * p1p2 * kernel);
+    T.bound = (beta * psi * rij * kernel);
     T.pres = (-pm * psi * (pres / (dens * dens)) * grad);
-    const R nu = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
-    const R nom = (R)fmax((double)dot(v1v2, p1p2), 0.0);
-    const R denom = dot(p1p2 / length(p1p2), p1p2 / length(p1p2)) + epsilon * ir * ir;
-    const R Pij = -nu * (nom / denom);
-    T.visc = (pm * psi * Pij * grad);
+    const R nuWall = (P.viscosity * ir * P.soundSpeed) / (dens * dens);
+    const R approach = (R)fmax((double)dot(vij, rij), 0.0);
+    const R normSq = dot(rij / length(rij), rij / length(rij)) + epsilon * ir * ir;
+    const R friction = -nuWall * (approach / normSq);
+    T.visc = (pm * psi * friction * grad);
     return T;
 }
 
@@ -583,10 +583,10 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
     const R kprg = P.kpress_grad, kvg = P.kvisc_grad, kvd = P.kvisc_denum;
     const R diameter = (R)(2.0 * P.particleRadius);
     const R diameter2 = diameter * diameter;
-    const R d1sq = dens * dens;
-    R kernel_diameter;
-    if (KSET == KS_MONAGHAN) kernel_diameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
-    else kernel_diameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
+    const R rhoSqOwn = dens * dens;
+    R wAtDiameter;
+    if (KSET == KS_MONAGHAN) wAtDiameter = Wmonaghan<R>(mk3<R>(diameter, 0, 0), ir);
+    else wAtDiameter = Wdefault<R>(mk3<R>(diameter, 0, 0), ir, kp);
     const R epsilon = (R)0.01;
     const R beta = P.beta, rd = P.restDensity;
     auto boundaryHit = [&](const BoundaryTerms<R, KSET> &T) {
@@ -595,39 +595,39 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         A.fvisc = A.fvisc - T.visc;
     };
     auto fluidHit = [&](uint32_t j) {
-        const V3<R> p1p2 = pos1 - xyz<R>(sPos[j]);
-        if (STRICT && ((j == self) || !(length(p1p2) < ir))) return; // the loop's own tests (:494,:505)
-        R prq2, mrho2; // pres2 / (dens2 * dens2), m2 / dens2
+        const V3<R> rij = pos1 - xyz<R>(sPos[j]);
+        if (STRICT && ((j == self) || !(length(rij) < ir))) return; // the loop's own tests (:494,:505)
+        R pOverRhoSqNb, mOverRhoNb; // pNb / (rhoNb * rhoNb), m2 / rhoNb
         if (PAIRS) {
             const PrePair<R> q = pairs[j];
-            prq2 = q.prq; mrho2 = q.mrho;
+            pOverRhoSqNb = q.prq; mOverRhoNb = q.mrho;
         } else {
-            const R dens2 = sDens[j];
-            const R pres2 = sPres[j];
-            const R d2sq = dens2 * dens2;
-            prq2 = pres2 / d2sq; mrho2 = m2 / dens2;
+            const R rhoNb = sDens[j];
+            const R pNb = sPres[j];
+            const R rhoSqNb = rhoNb * rhoNb;
+            pOverRhoSqNb = pNb / rhoSqNb; mOverRhoNb = m2 / rhoNb;
         }
-        const V3<R> v1v2 = vel1 - xyz<R>(sVel[j]);
-        V3<R> kpressure_grad, kvisco_grad;
+        const V3<R> vij = vel1 - xyz<R>(sVel[j]);
+        V3<R> gradSpiky, gradVisc;
         R kernel;
         if (KSET == KS_MONAGHAN) {
-            kpressure_grad = Wmonaghan_grad<R>(p1p2, ir);
-            kvisco_grad = kpressure_grad;
-            kernel = Wmonaghan<R>(p1p2, ir);
+            gradSpiky = Wmonaghan_grad<R>(rij, ir);
+            gradVisc = gradSpiky;
+            kernel = Wmonaghan<R>(rij, ir);
         } else {
-            kpressure_grad = Wpressure_grad<R>(p1p2, ir, kprg);
-            kvisco_grad = Wviscosity_grad<R>(p1p2, ir, kvg, kvd);
-            kernel = Wdefault<R>(p1p2, ir, kp);
+            gradSpiky = Wpressure_grad<R>(rij, ir, kprg);
+            gradVisc = Wviscosity_grad<R>(rij, ir, kvg, kvd);
+            kernel = Wdefault<R>(rij, ir, kp);
         }
-        A.fpres = A.fpres + (m2 * (pres / d1sq + prq2) * kpressure_grad);
-        const R a = dot(p1p2, kvisco_grad);
-        const R b = dot(p1p2, p1p2) + 0.01f * (ir * ir);
-        A.fvisc = A.fvisc + (mrho2 * v1v2 * (a / b));
+        A.fpres = A.fpres + (m2 * (pres / rhoSqOwn + pOverRhoSqNb) * gradSpiky);
+        const R a = dot(rij, gradVisc);
+        const R b = dot(rij, rij) + 0.01f * (ir * ir);
+        A.fvisc = A.fvisc + (mOverRhoNb * vij * (a / b));
         if (SURF) {
             V3<R> ai = mk3<R>(0, 0, 0);
-            const R r2 = dot(p1p2, p1p2);
-            if (r2 > diameter2) ai = ai - (kappa / pm * pm * p1p2 * kernel);
-            else ai = ai - (kappa / pm * pm * p1p2 * kernel_diameter);
+            const R r2 = dot(rij, rij);
+            if (r2 > diameter2) ai = ai - (kappa / pm * pm * rij * kernel);
+            else ai = ai - (kappa / pm * pm * rij * wAtDiameter);
             A.fsurf = A.fsurf + ai;
         }
     };

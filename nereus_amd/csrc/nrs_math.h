@@ -74,30 +74,30 @@ template <typename R> NRS_DEV V3<R> Wdefault_grad(V3<R> r, R h, R kpoly_grad)
 // spiky gradient (:121-135)
 template <typename R> NRS_DEV V3<R> Wpressure_grad(V3<R> r, R h, R kpress_grad)
 {
-    R l_r = length(r);
-    R r2 = l_r * l_r;
+    R rlen = length(r);
+    R r2 = rlen * rlen;
     R h2 = h * h;
     if (r2 > h2) return mk3<R>(0, 0, 0);
-    R c = (h - l_r) * (h - l_r);
-    return kpress_grad * (r / l_r) * c;
+    R c = (h - rlen) * (h - rlen);
+    return kpress_grad * (r / rlen) * c;
 }
 // viscosity kernel "gradient" (:140-154)
 template <typename R> NRS_DEV V3<R> Wviscosity_grad(V3<R> r, R h, R kvisc_grad, R kvisc_denum)
 {
-    R l_r = length(r);
-    R r2 = l_r * l_r;
+    R rlen = length(r);
+    R r2 = rlen * rlen;
     R h2 = h * h;
     if (r2 > h2) return mk3<R>(0, 0, 0);
-    R c = -(3 * l_r / kvisc_denum) + (2 / (h2)) - (h / (2 * l_r * l_r * l_r));
+    R c = -(3 * rlen / kvisc_denum) + (2 / (h2)) - (h / (2 * rlen * rlen * rlen));
     return kvisc_grad * r * c;
 }
 // Monaghan cubic spline (:159-203); constants evaluated in double as the host compiler does
 template <typename R> NRS_DEV R Wmonaghan(V3<R> r, R h)
 {
     R value = (R)0.0;
-    R m_invH = (R)(1.0 / h);
+    R invH = (R)(1.0 / h);
     R m_v = (R)(1.0 / (4.0 * 3.14159265358979323846 * h * h * h));
-    R q = length(r) * m_invH;
+    R q = length(r) * invH;
     if (q >= 0 && q < 1)
         value = m_v * ((2 - q) * (2 - q) * (2 - q) - 4.0f * (1 - q) * (1 - q) * (1 - q));
     else if (q >= 1 && q < 2)
@@ -110,16 +110,16 @@ template <typename R> NRS_DEV V3<R> Wmonaghan_grad(V3<R> r, R h)
 {
     R m_g = (R)(1.0 / (4.0 * 3.14159265358979323846 * h * h * h));
     R dist = length(r);
-    R m_invH = (R)(1.0 / h);
-    R q = dist * m_invH;
+    R invH = (R)(1.0 / h);
+    R q = dist * invH;
     V3<R> gradient = mk3<R>(0, 0, 0);
     if (q >= 0 && q < 1) {
         R scalar = -3.0f * (2 - q) * (2 - q);
         scalar += 12.0f * (1 - q) * (1 - q);
-        gradient = (m_g * m_invH * scalar / dist) * r;
+        gradient = (m_g * invH * scalar / dist) * r;
     } else if (q >= 1 && q < 2) {
         R scalar = -3.0f * (2 - q) * (2 - q);
-        gradient = (m_g * scalar * m_invH / dist) * r;
+        gradient = (m_g * scalar * invH / dist) * r;
     }
     return gradient;
 }
