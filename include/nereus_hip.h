@@ -270,9 +270,15 @@ int nrs_stage_ms(nrs_ctx *ctx, int stage, float *ms, uint32_t *launches);
  * Pass NULL for the neighbour that does not exist (ends of the chain).  IISPH contexts: halo_cells >= 8 and the step is driven
  * through nrs_iisph_predict / _iterate / _finish (below). */
 int nrs_slab_configure(nrs_ctx *ctx, int32_t cell_lo, int32_t cell_hi, int32_t halo_cells);
-/* counts (optional) receives {stay, migrate-left, halo-left, migrate-right, halo-right, ghost}. */
+/* counts (optional) receives {stay, migrate-left, halo-left, migrate-right, halo-right, ghost}.
+ * With counts == NULL nrs_slab_pack does not wait for the device: the two messages are complete in stream order when it returns (the
+ * caller enqueues its sends on the same stream right behind it), and the stream populations are read back together with the headers of
+ * the received messages inside nrs_slab_unpack — ONE host synchronisation per exchange.  A message-capacity overflow is then reported
+ * by nrs_slab_unpack (or by whichever call on the context comes first) with NRS_E_CAPACITY.  nrs_slab_last_counts returns the counts
+ * of the last pack afterwards.  Passing counts makes nrs_slab_pack wait for them itself. */
 int nrs_slab_pack(nrs_ctx *ctx, void *send_left, void *send_right, uint64_t capacity, uint32_t counts[6]);
 int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right, uint64_t capacity);
+int nrs_slab_last_counts(nrs_ctx *ctx, uint32_t counts[6]);
 /* owned particles (the first nrs_num_owned() entries of NRS_ARR_POS/VEL right after nrs_slab_pack/unpack) */
 uint64_t nrs_num_owned(nrs_ctx *ctx);
 uint64_t nrs_slab_message_bytes(uint64_t capacity, int precision);

@@ -54,6 +54,7 @@ EXPORTS = [
     "nrs_max_velocity", "nrs_slab_configure", "nrs_slab_pack", "nrs_slab_unpack", "nrs_num_owned",
     "nrs_slab_message_bytes", "nrs_slab_histogram", "nrs_resort_stats", "nrs_snapshot_begin", "nrs_snapshot_wait",
     "nrs_get_stat", "nrs_boundary_volumes", "nrs_eval_smoothing", "nrs_iisph_predict", "nrs_iisph_iterate", "nrs_iisph_finish",
+    "nrs_slab_last_counts",
 ]
 
 
@@ -111,6 +112,7 @@ def load_library(path=None):
     lib.nrs_slab_configure.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     lib.nrs_slab_pack.argtypes = [vp, vp, vp, u64, C.POINTER(C.c_uint32)]
     lib.nrs_slab_unpack.argtypes = [vp, vp, vp, u64]
+    lib.nrs_slab_last_counts.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.nrs_num_owned.argtypes = [vp]
     lib.nrs_num_owned.restype = u64
     lib.nrs_slab_message_bytes.argtypes = [u64, i32]
@@ -298,9 +300,18 @@ class Solver:
     def slab_configure(self, cell_lo, cell_hi, halo_cells=2):
         self._chk(self.lib.nrs_slab_configure(self.h, int(cell_lo), int(cell_hi), int(halo_cells)))
 
-    def slab_pack(self, send_left_ptr, send_right_ptr, capacity):
+    def slab_pack(self, send_left_ptr, send_right_ptr, capacity, want_counts=True):
+        """want_counts=False: do not wait for the device (the counts are read back inside slab_unpack; slab_last_counts())"""
+        if not want_counts:
+            self._chk(self.lib.nrs_slab_pack(self.h, send_left_ptr, send_right_ptr, int(capacity), None))
+            return None
         counts = (C.c_uint32 * 6)()
         self._chk(self.lib.nrs_slab_pack(self.h, send_left_ptr, send_right_ptr, int(capacity), counts))
+        return list(counts)
+
+    def slab_last_counts(self):
+        counts = (C.c_uint32 * 6)()
+        self._chk(self.lib.nrs_slab_last_counts(self.h, counts))
         return list(counts)
 
     def slab_unpack(self, recv_left_ptr, recv_right_ptr, capacity):

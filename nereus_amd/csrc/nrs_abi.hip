@@ -77,6 +77,19 @@ struct nrs_ctx {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return pending == 0 && !busy; });
     }
+    // for the entry points that cannot report an error: run the deferred bookkeeping, park its error for the next call that can
+    void settle_keep_error()
+    {
+        const int rc = impl->settle();
+        if (rc == NRS_OK) return;
+        std::lock_guard<std::mutex> lk(m);
+        if (err == NRS_OK) { err = rc; errMsg = g_err; }
+    }
+    bool failed()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        return err != NRS_OK;
+    }
     bool idle()
     {
         std::lock_guard<std::mutex> lk(m);
@@ -103,6 +116,12 @@ struct nrs_ctx {
 };
 
 #define CTX_GUARD(ctx)                                                   \
+    if (!(ctx) || !(ctx)->impl) return fail(NRS_E_INVALID, "NULL context"); \
+    if (hipSetDevice((ctx)->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed"); \
+    { const int drc_ = (ctx)->drain(); if (drc_ != NRS_OK) return drc_; } \
+    { const int src_ = (ctx)->impl->settle(); if (src_ != NRS_OK) return src_; }
+// (the two entry points of the exchange itself: nrs_slab_pack queues, nrs_slab_unpack settles together with its own wait)
+#define CTX_GUARD_EXCHANGE(ctx)                                          \
     if (!(ctx) || !(ctx)->impl) return fail(NRS_E_INVALID, "NULL context"); \
     if (hipSetDevice((ctx)->impl->device) != hipSuccess) return fail(NRS_E_HIP, "hipSetDevice failed"); \
     { const int drc_ = (ctx)->drain(); if (drc_ != NRS_OK) return drc_; }
@@ -184,6 +203,7 @@ uint64_t nrs_num_particles(nrs_ctx *ctx)
 {
     if (!ctx || !ctx->impl) return 0;
     ctx->wait_idle();
+    ctx->settle_keep_error();
     return ctx->impl->get_n();
 }
 int nrs_set_boundaries(nrs_ctx *ctx, const void *bi4, const void *vbi, uint64_t nb, int update_grid)
@@ -203,7 +223,10 @@ int nrs_step(nrs_ctx *ctx, int nsteps)
         if (nsteps <= 1) return ctx->impl->step(nsteps, 0);
         NRSCHK(ctx->impl->step(0, 0));
     }
-    ctx->submit(nsteps); // (behind steps that are still being enqueued: their checks cover these too)
+    // (behind steps that are still being enqueued: their checks cover these too; if one of them has already failed, report that now
+    // instead of queueing more work on a state the failed step left behind)
+    if (ctx->failed()) return ctx->drain();
+    ctx->submit(nsteps);
     return NRS_OK;
 }
 int nrs_step_partial(nrs_ctx *ctx, int stop_stage)
@@ -284,18 +307,25 @@ int nrs_slab_configure(nrs_ctx *ctx, int32_t cell_lo, int32_t cell_hi, int32_t h
 }
 int nrs_slab_pack(nrs_ctx *ctx, void *send_left, void *send_right, uint64_t capacity, uint32_t counts[6])
 {
-    CTX_GUARD(ctx);
+    CTX_GUARD_EXCHANGE(ctx);
     return ctx->impl->slab_pack(send_left, send_right, capacity, counts);
 }
 int nrs_slab_unpack(nrs_ctx *ctx, const void *recv_left, const void *recv_right, uint64_t capacity)
 {
-    CTX_GUARD(ctx);
+    CTX_GUARD_EXCHANGE(ctx);
     return ctx->impl->slab_unpack(recv_left, recv_right, capacity);
+}
+int nrs_slab_last_counts(nrs_ctx *ctx, uint32_t counts[6])
+{
+    CTX_GUARD(ctx);
+    if (!counts) return fail(NRS_E_INVALID, "NULL argument");
+    return ctx->impl->slab_last_counts(counts);
 }
 uint64_t nrs_num_owned(nrs_ctx *ctx)
 {
     if (!ctx || !ctx->impl) return 0;
     ctx->wait_idle();
+    ctx->settle_keep_error();
     return ctx->impl->num_owned();
 }
 int nrs_slab_histogram(nrs_ctx *ctx, int32_t first_cell, uint32_t ncells, uint32_t *counts)

@@ -93,6 +93,8 @@ struct CtxBase {
     virtual void resort_stats(uint64_t *steps, uint64_t *fallbacks) = 0;
     virtual int get_stat(int which, double *out) = 0;
     virtual int iisph_phase(int phase, double *sum, uint64_t *count) = 0;
+    virtual int settle() = 0;                           // finish host bookkeeping a previous call deferred (nrs_slab_pack's totals)
+    virtual int slab_last_counts(uint32_t *counts) = 0; // stream populations of the last nrs_slab_pack
     virtual int set_profiling(uint32_t mask) = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;

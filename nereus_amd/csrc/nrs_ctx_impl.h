@@ -1233,6 +1233,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
         if (midStep) return fail(NRS_E_STATE, "state is mid-update");
         if (mcap == 0 || mcap > (uint64_t)HIT_INDEX) return fail(NRS_E_INVALID, "bad message capacity");
+        NRSCHK(finish_pack());   // (a pack right behind a pack whose totals nobody has looked at yet)
         NRSCHK(compact_holes()); // (a pack right after a pack/unpack without a step in between)
         if (iisphPhase) return fail(NRS_E_STATE, "a host-driven IISPH step is in progress");
         if (iisph() && n) // the warm-start pressure travels in vel.w (k_pressure_to_velw)
@@ -1243,12 +1244,12 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(slabTotals.alloc(ST_TOTALS * 4));
         NRSCHK(ghostPos.alloc(sizeof(T4) * mcap));
         NRSCHK(ghostVel.alloc(sizeof(T4) * mcap));
-        uint32_t tot[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
         bool inplace = false;
+        if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 128, hipHostMallocDefault));
         if (N) {
-            if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 64, hipHostMallocDefault));
             const bool fusedClass = classifiedValid && slotOrderValid && classifiedN == N && rsMovers.p && hashCur && hashNext &&
                                     hashNext != hashCur;
+            classifiedValidAtPack = fusedClass;
             if (fusedClass) {
                 // the force kernel of the last step classified every slot for these cuts (flags, stream populations per
                 // 2048 slots, dead marks in the keys, movers / dead per 256 slots): scan, copy out the few particles of
@@ -1274,17 +1275,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 const uint32_t nTiles = nblocks(N);
                 NRSCHK(launch_resort_scan(nTiles, true)); // also totals the cell changers and the dead slots
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, ST_TOTALS * 4, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipMemcpyAsync(slabHostTotals + 8, rsScalars.p, 16, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipEventRecord(packEvent, stream));
                 hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
                                    offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
                 HIPCHK(hipGetLastError());
                 rsTilesDirty = false; // the scan resets the counts it reads
-                HIPCHK(hipEventSynchronize(packEvent));
-                std::memcpy(tot, slabHostTotals, sizeof(tot));
-                tot[ST_CHANGED] = slabHostTotals[8 + 1];
-                tot[ST_STAY] = N - slabHostTotals[8 + 2];
             } else {
                 // coherent re-sort of the next step: possible when the arrays are still in the slot order of the last sort and
                 // the fused force kernel left the new keys per slot
@@ -1324,34 +1321,64 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
                 HIPCHK(hipGetLastError());
                 // page-locked destination: the copy is complete when the event behind it is (a pageable destination is only
                 // guaranteed after a stream synchronization, which would also wait for the split queued below)
-                if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 64, hipHostMallocDefault));
-                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, sizeof(tot), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(slabHostTotals, slabTotals.p, ST_TOTALS * 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipEventRecord(packEvent, stream));
                 if (inplace) {
                     // the split of the slots we keep does not depend on what arrives: queue it now, so that it runs while the
-                    // host reads the totals and the messages travel
-                    HIPCHK(hipEventRecord(packEvent, stream));
+                    // messages travel
                     const uint32_t nTiles = nblocks(N);
                     NRSCHK(launch_resort_scan(nTiles, true));
                     hipLaunchKernelGGL((k_resort_split<true>), dim3(nTiles), dim3(BLOCK), 0, stream, hashCur, hashNext, offsets_movers(),
                                        offsets_dead(), rsMovers.as<uint64_t>(), rsStayers.as<uint64_t>(), N, (uint32_t *)nullptr);
                     HIPCHK(hipGetLastError());
                     rsTilesDirty = false; // the scan resets the counts it reads
-                    HIPCHK(hipEventSynchronize(packEvent));
-                } else {
-                    HIPCHK(hipStreamSynchronize(stream));
                 }
-                std::memcpy(tot, slabHostTotals, sizeof(tot));
             }
         } else {
             HIPCHK(hipMemsetAsync(slabTotals.p, 0, ST_TOTALS * 4, stream));
             hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, stream, slabTotals.as<uint32_t>(), (unsigned char *)sendL,
                                (unsigned char *)sendR);
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipEventRecord(packEvent, stream));
+        }
+        // Round 3: nothing above waits.  The messages are complete in stream order, so the caller can enqueue its sends right behind
+        // this call; the stream totals (how many stay, leave, ghost) are read back by finish_pack() — in nrs_slab_unpack, together
+        // with the headers of the received messages: ONE host synchronisation per exchange instead of two — or by whichever entry
+        // point needs the particle count first (settle()).
+        packPending = true;
+        pendFused = N && classifiedValidAtPack;
+        pendInplace = inplace;
+        pendN = N;
+        pendCap = mcap;
+        if (counts) { // the caller wants the counts now: that is the synchronisation it asked for
+            NRSCHK(finish_pack());
+            std::memcpy(counts, lastCounts, ST_COUNT * sizeof(uint32_t));
+        }
+        return NRS_OK;
+    }
+    // ---- the host half of nrs_slab_pack, run when the stream totals are needed ---------------------------------------------
+    bool packPending = false, pendFused = false, pendInplace = false, classifiedValidAtPack = false;
+    uint32_t pendN = 0;
+    uint64_t pendCap = 0;
+    uint32_t lastCounts[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    int finish_pack()
+    {
+        if (!packPending) return NRS_OK;
+        packPending = false;
+        const uint32_t N = pendN;
+        const bool inplace = pendInplace;
+        uint32_t tot[ST_TOTALS] = {0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipEventSynchronize(packEvent));
+        if (N) {
+            std::memcpy(tot, slabHostTotals, sizeof(tot));
+            if (pendFused) { // (pre-classified partition: cell changers and dead slots come from the re-sort's scan)
+                tot[ST_CHANGED] = slabHostTotals[8 + 1];
+                tot[ST_STAY] = N - slabHostTotals[8 + 2];
+            }
         }
         if ((uint64_t)tot[ST_STAY] + tot[ST_MIG_L] + tot[ST_MIG_R] > N || tot[ST_CHANGED] > tot[ST_STAY])
             return fail(NRS_E_HIP, "inconsistent slab stream totals");
-        const bool overflow = (uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > mcap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > mcap ||
-                              tot[ST_GHOST] > mcap;
+        const bool overflow = (uint64_t)tot[ST_MIG_L] + tot[ST_HALO_L] > pendCap || (uint64_t)tot[ST_MIG_R] + tot[ST_HALO_R] > pendCap ||
+                              tot[ST_GHOST] > pendCap;
         to_fresh();
         if (inplace) {
             // hashNext / indexNext hold key and slot of every live slot, 0xffffffff marks the dead ones; arrivals are added to the mover
@@ -1367,8 +1394,15 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         nOwned = n;
         ghostCount = tot[ST_GHOST];
         packChanged = tot[ST_CHANGED];
-        if (counts) std::memcpy(counts, tot, ST_COUNT * sizeof(uint32_t));
+        std::memcpy(lastCounts, tot, ST_COUNT * sizeof(uint32_t));
         if (overflow) return fail(NRS_E_CAPACITY, "slab message capacity exceeded");
+        return NRS_OK;
+    }
+    int settle() override { return finish_pack(); }
+    int slab_last_counts(uint32_t *counts) override
+    {
+        NRSCHK(finish_pack());
+        std::memcpy(counts, lastCounts, ST_COUNT * sizeof(uint32_t));
         return NRS_OK;
     }
     uint32_t cap_blocks() const { return (uint32_t)((cap + SLAB_TILE - 1) / SLAB_TILE); }
@@ -1378,10 +1412,16 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(validate("nrs_slab_unpack"));
         NRSCHK(refuse_mid_iisph("nrs_slab_unpack"));
         if (!slabOn) return fail(NRS_E_STATE, "nrs_slab_configure first");
+        // ONE host synchronisation for the exchange: the headers of the received messages (how many migrants, how many halo copies)
+        // are copied to page-locked memory behind the receives, and the same wait covers the stream totals of the pack (finish_pack)
         uint32_t hL[4] = {0, 0, 0, 0}, hR[4] = {0, 0, 0, 0};
-        if (recvL) HIPCHK(hipMemcpyAsync(hL, recvL, 16, hipMemcpyDeviceToHost, stream));
-        if (recvR) HIPCHK(hipMemcpyAsync(hR, recvR, 16, hipMemcpyDeviceToHost, stream));
+        if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 128, hipHostMallocDefault));
+        if (recvL) HIPCHK(hipMemcpyAsync(slabHostTotals + 16, recvL, 16, hipMemcpyDeviceToHost, stream));
+        if (recvR) HIPCHK(hipMemcpyAsync(slabHostTotals + 20, recvR, 16, hipMemcpyDeviceToHost, stream));
         if (recvL || recvR) HIPCHK(hipStreamSynchronize(stream));
+        if (recvL) std::memcpy(hL, slabHostTotals + 16, 16);
+        if (recvR) std::memcpy(hR, slabHostTotals + 20, 16);
+        NRSCHK(finish_pack());
         if ((uint64_t)hL[0] + hL[1] > mcap || (uint64_t)hR[0] + hR[1] > mcap) return fail(NRS_E_INVALID, "corrupt slab message header");
         const bool inplace = packInplace && holesPending;
         const uint64_t arrivals = (uint64_t)hL[0] + hR[0] + ghostCount + hL[1] + hR[1];

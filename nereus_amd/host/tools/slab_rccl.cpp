@@ -105,8 +105,7 @@ int main(int argc, char **argv)
     HIP_OK(hipMalloc((void **)&redDev, 2 * sizeof(double)));
 
     auto exchange = [&]() {
-        uint32_t counts[6];
-        NRS_OK_(nrs_slab_pack(ctx, sendL, sendR, msgCap, counts));
+        NRS_OK_(nrs_slab_pack(ctx, sendL, sendR, msgCap, nullptr)); // (no counts: the call does not wait, the sends follow in stream order)
         // one fixed-size message per neighbour and direction, all four in one group (xGMI is point to point: only the two
         // nearest-neighbour links carry traffic)
         NCCL_OK(ncclGroupStart());

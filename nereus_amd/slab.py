@@ -124,8 +124,13 @@ class HipSlabEngine:
         self._configured = True
 
     def pack(self, send_left, send_right):
+        """queues the partition and returns None: the counts are read back with the received headers in unpack() (one host
+        synchronisation per exchange); last_counts() has them afterwards"""
         return self.solver.slab_pack(None if send_left is None else send_left.data_ptr(),
-                                     None if send_right is None else send_right.data_ptr(), self.msg_capacity)
+                                     None if send_right is None else send_right.data_ptr(), self.msg_capacity, want_counts=False)
+
+    def last_counts(self):
+        return self.solver.slab_last_counts()
 
     def unpack(self, recv_left, recv_right):
         self.solver.slab_unpack(None if recv_left is None else recv_left.data_ptr(),
@@ -199,7 +204,7 @@ class SlabDriver:
 
     def _exchange(self):
         dist, eng = self.dist, self.engine
-        self.last_counts = eng.pack(self.send_l, self.send_r)
+        counts = eng.pack(self.send_l, self.send_r)   # (None from the product engine: it does not wait here)
         ops, host = [], {}
         def wire(t):
             if not self.stage or t is None:
@@ -225,6 +230,7 @@ class SlabDriver:
             if rr is not None:
                 self.recv_r.copy_(rr)
         eng.unpack(self.recv_l, self.recv_r)
+        self.last_counts = counts if counts is not None else eng.last_counts()
 
     def step(self, k=1):
         for _ in range(k):

@@ -193,12 +193,23 @@ static inline SReal Aboundary(SVec3 r, SReal h, SReal bpol)               /* :23
 #endif
 
 /* ---- grid: sph/sph_kernel_impl.cuh:105-125 ------------------------------------------------ */
+/* `(int)` of a float ON THE DEVICE: CUDA converts with cvt.rzi.s32.f32 — NaN gives 0, values beyond the int range saturate — and so does
+ * gfx950's v_cvt_i32_f32; in C++ on the host the same cast is undefined for those inputs (x86 returns INT_MIN for all of them).  The
+ * path being restated is the CUDA one, so the oracle converts as the devices do.  Only particles with NaN / inf / absurd coordinates
+ * (a caller's bug) are affected: which cell they are hashed into. */
+static inline int device_f2i(SReal v)
+{
+    if (v != v) return 0;
+    if (v >= (SReal)2147483648.0) return 2147483647;
+    if (v <= (SReal)-2147483648.0) return (int)(-2147483647 - 1);
+    return (int)v;
+}
 static inline I3 calcGridPos(const SphSimParams &P, SVec3 p)
 {
     I3 g;
-    g.x = (int)std::floor((p.x - P.worldOrigin.x) / P.cellSize.x);
-    g.y = (int)std::floor((p.y - P.worldOrigin.y) / P.cellSize.y);
-    g.z = (int)std::floor((p.z - P.worldOrigin.z) / P.cellSize.z);
+    g.x = device_f2i(std::floor((p.x - P.worldOrigin.x) / P.cellSize.x));
+    g.y = device_f2i(std::floor((p.y - P.worldOrigin.y) / P.cellSize.y));
+    g.z = device_f2i(std::floor((p.z - P.worldOrigin.z) / P.cellSize.z));
     return g;
 }
 static inline unsigned umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }

@@ -34,8 +34,9 @@ def main():
         eng.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            counts = eng.pack(send_l, send_r)
+            eng.pack(send_l, send_r)
             eng.unpack(None, None)
+            counts = eng.last_counts()
             eng.step(1)
         eng.synchronize()
         dt = time.perf_counter() - t0

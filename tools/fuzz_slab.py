@@ -71,8 +71,7 @@ def one(seed, iisph=False):
     def exchange():
         for r, e in enumerate(engs):
             with torch.cuda.stream(e.stream):
-                c_ = e.pack(bufs[r]["sl"], bufs[r]["sr"])
-                STATS["migrants"] += int(c_[1]) + int(c_[3])
+                e.pack(bufs[r]["sl"], bufs[r]["sr"])   # (does not wait: the counts are read back in unpack)
         torch.cuda.synchronize()
         for r in range(world):
             if r > 0: bufs[r]["rl"].copy_(bufs[r - 1]["sr"])
@@ -81,6 +80,8 @@ def one(seed, iisph=False):
         for r, e in enumerate(engs):
             with torch.cuda.stream(e.stream):
                 e.unpack(bufs[r]["rl"], bufs[r]["rr"])
+                c_ = e.last_counts()
+                STATS["migrants"] += int(c_[1]) + int(c_[3])
     try:
         for it in range(steps):
             if it and rng.random() < 0.35:   # a re-cut: one interior cut moves by one or two cells (both neighbours are told before the exchange)
