@@ -1246,6 +1246,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ghostVel.alloc(sizeof(T4) * mcap));
         bool inplace = false;
         if (!slabHostTotals) HIPCHK(hipHostMalloc((void **)&slabHostTotals, 128, hipHostMallocDefault));
+        if (!packEvent) HIPCHK(hipEventCreateWithFlags(&packEvent, hipEventDisableTiming)); // (contexts without re-sort buffers have none yet)
         if (N) {
             const bool fusedClass = classifiedValid && slotOrderValid && classifiedN == N && rsMovers.p && hashCur && hashNext &&
                                     hashNext != hashCur;

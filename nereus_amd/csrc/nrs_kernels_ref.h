@@ -13,6 +13,7 @@
 // thread mapping, memory layout, templates, boundary packing, double-buffered P_l — is this build's own.
 #pragma once
 #include "nrs_math.h"
+#include <climits>
 
 namespace nrs {
 
@@ -45,6 +46,9 @@ template <typename R> NRS_DEV bool run_ok(const GridView<R> &G, uint32_t a, uint
 
 template <typename R> NRS_DEV bool slab_active(const Params<R> &P, const GridView<R> &G, R x)
 {
+    // (a single-domain context has no inactive range: without the first test a particle with x = +inf — its cell index saturates past
+    // INT_MAX — would be skipped, where the reference gives it its self term; found by the randomised soak against the oracle, round 3)
+    if (G.actLo == INT_MIN) return true;
     const long long cx = (long long)floor((x - P.worldOrigin[0]) / P.cellSize[0]);
     return cx >= (long long)G.actLo && cx < (long long)G.actHi;
 }

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
                 }
             }
         }
-        hc.nf = nf; hc.nb = nb; hc.over = nf + nb > HIT_CAP;
+        // (an owner with a NaN / inf coordinate takes the reference-order walk: see Sweep::scan)
+        const bool finiteOwner = (fabsf(p.x) < INFINITY) & (fabsf(p.y) < INFINITY) & (fabsf(p.z) < INFINITY);
+        hc.nf = nf; hc.nb = nb; hc.over = (nf + nb > HIT_CAP) | !finiteOwner;
     } else {
         // grid-edge cells or hulls longer than the pool: the global-memory scan of nrs_kernels_tiled.h, its 32-bit lists in the
         // (unused) pool

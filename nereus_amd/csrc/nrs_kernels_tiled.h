@@ -232,7 +232,12 @@ template <typename R> struct Sweep {
             }
         }
         HitCounts hc;
-        hc.nf = nf; hc.nb = nb; hc.over = over; hc.anyB = anyB;
+        // An owner with a NaN / inf coordinate (a caller's bug) fails every distance test, so its lists are empty — but the reference's
+        // loops without a cut-off (boundary particles in the force loop) multiply its infinite distances into their sums
+        // (0 * inf = NaN): such an owner takes the reference-order walk, as a list overflow does.  (Found by the randomised soak,
+        // round 3: seed 20728, a particle with y = inf next to a wall sheet.)
+        const bool finite = (fabs(p.x) < (R)INFINITY) & (fabs(p.y) < (R)INFINITY) & (fabs(p.z) < (R)INFINITY); // (false for NaN too)
+        hc.nf = nf; hc.nb = nb; hc.over = over | !finite; hc.anyB = anyB;
         return hc;
     }
 
