@@ -34,6 +34,7 @@
 #pragma once
 #include "nrs_kernels_ref.h"
 #include "nrs_kernels_slab.h"
+#include <type_traits>
 
 namespace nrs {
 
@@ -54,6 +55,9 @@ struct CutThresholds { float lenLtIr, r2LeH2; };
 // boundaries) and measured 0.487 -> 0.465 ms at 10 M particles; 8 (64 VGPRs) spills into the hit loop: 0.563 ms
 #ifndef FORCES_LISTS_MIN_WAVES
 #define FORCES_LISTS_MIN_WAVES 7
+#endif
+#ifndef FORCES_PACKED_MIN_WAVES
+#define FORCES_PACKED_MIN_WAVES 5
 #endif
 // value of `v` in lane `srcLane` (wave-uniform lane number), for every lane
 NRS_DEV float bcast_lane(float v, int srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane)); }
@@ -572,6 +576,106 @@ NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3
     return T;
 }
 
+// ---- two hits per iteration on packed fp32 (fp32, Muller kernels, interior code without boundary hits) ---------------------------
+// gfx950 executes v_pk_mul_f32 / v_pk_add_f32 on two floats per lane and instruction, IEEE-rounded like their scalar forms.  The hit
+// loop of the force walk is bound by vector-instruction issue, so two CONSECUTIVE hits of a particle are
+// evaluated side by side — component .x of every pair is hit k, .y is hit k + 1 — with exactly the scalar code's operations in the
+// scalar code's order per hit; the divisions, square roots and the double-precision cube stay scalar (no packed forms exist), the
+// running sums are formed hit k first, then hit k + 1, as before: bit-identical by construction, checked against the reference-order
+// kernels by the whole suite.
+// Measured on the bench's own state (NS scene after 3000 steps at dt = 2.5e-4 s, tools/ab_flowing.sh): force stage 1.078 -> 0.887 ms
+// (-18 %) with 94 VGPRs / 5 waves per SIMD; bounded to 80 / 72 VGPRs it spills into the loop and loses (1.11 / 1.45 ms); at rest (six
+// hits per particle) 0.386 ms either way.  368 -> 272 vector instructions per two hits.
+#ifndef NRS_PACKED_HITS
+#define NRS_PACKED_HITS 1
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V3x2 { f2 x, y, z; };
+NRS_DEV f2 splat2(float v) { f2 r = {v, v}; return r; }
+NRS_DEV f2 pair2(float a, float b) { f2 r = {a, b}; return r; }
+NRS_DEV f2 dot2(const V3x2 &a, const V3x2 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // ((x + y) + z), as dot()
+// Two IEEE divisions a.x / b.x, a.y / b.y.  The compiler expands a correctly rounded fp32 division into v_div_scale (x2), v_rcp, five
+// fused multiply-adds and a multiply, v_div_fmas, v_div_fixup (AMDGPU LowerFDIV32); here the six arithmetic steps of the two
+// divisions run as v_pk_fma_f32 / v_pk_mul_f32 on both at once — the same operations on the same operands, 16 instructions instead
+// of 22, the quotients are the correctly rounded ones either way (tools/check_div2.hip: all 2^32 numerators for twelve denominators and
+// 2^32 random operand pairs incl. zeros, denormals, infinities, NaNs: 0 differing quotients).  Bit-identical — and SLOWER: the force stage
+// 1.053 ms against 0.887 ms with the compiler's own expansion (two more registers tip the 96-VGPR bound into spills; at 4 waves, no
+// spills: 0.912 ms — the hand-ordered chain leaves the scheduler less to interleave).  Kept behind the macro, off.
+#ifndef NRS_PACKED_DIV
+#define NRS_PACKED_DIV 0
+#endif
+NRS_DEV f2 div2(f2 a, f2 b)
+{
+#if NRS_PACKED_DIV
+    bool da, db, na, nb;
+    const f2 den = pair2(__builtin_amdgcn_div_scalef(a.x, b.x, false, &da), __builtin_amdgcn_div_scalef(a.y, b.y, false, &db));
+    const f2 num = pair2(__builtin_amdgcn_div_scalef(a.x, b.x, true, &na), __builtin_amdgcn_div_scalef(a.y, b.y, true, &nb));
+    const f2 rcp = pair2(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y));
+    const f2 nden = -den;
+    const f2 e0 = __builtin_elementwise_fma(nden, rcp, splat2(1.0f));
+    const f2 y = __builtin_elementwise_fma(e0, rcp, rcp);
+    const f2 q0 = num * y;
+    const f2 e1 = __builtin_elementwise_fma(nden, q0, num);
+    const f2 q1 = __builtin_elementwise_fma(e1, y, q0);
+    const f2 e2 = __builtin_elementwise_fma(nden, q1, num);
+    const float qa = __builtin_amdgcn_div_fmasf(e2.x, y.x, q1.x, na);
+    const float qb = __builtin_amdgcn_div_fmasf(e2.y, y.y, q1.y, nb);
+    return pair2(__builtin_amdgcn_div_fixupf(qa, b.x, a.x), __builtin_amdgcn_div_fixupf(qb, b.y, a.y));
+#else
+    return pair2(a.x / b.x, a.y / b.y);
+#endif
+}
+struct PairTerms2 { V3x2 pres, visc, surf; };
+// the three pair terms of computeCellForces (sph_kernel_impl.cuh:520-548) for hits (a, b) of one owner; `own` = pres / (dens * dens)
+// of the owner, c0 = kappa / pm * pm, both formed once per owner with the scalar code's operations
+template <bool SURF>
+NRS_DEV PairTerms2 fluid_terms2_muller(const Params<float> &P, V3<float> pos1, V3<float> vel1, float own, float c0, float wAtDiameter, float diameter2,
+                                       float4 pa, float4 pb, float4 va, float4 vb, PrePair<float> qa, PrePair<float> qb)
+{
+    const float ir = P.interactionRadius, m2 = P.particleMass;
+    const V3x2 r = {splat2(pos1.x) - pair2(pa.x, pb.x), splat2(pos1.y) - pair2(pa.y, pb.y), splat2(pos1.z) - pair2(pa.z, pb.z)};
+    const V3x2 v = {splat2(vel1.x) - pair2(va.x, vb.x), splat2(vel1.y) - pair2(va.y, vb.y), splat2(vel1.z) - pair2(va.z, vb.z)};
+    const f2 d2 = dot2(r, r);                       // dot(rij, rij)
+    const f2 len = pair2(sqrt_rn(d2.x), sqrt_rn(d2.y)); // length(rij)
+    const f2 r2 = len * len;
+    const float h2 = ir * ir;
+    const bool outA = r2.x > h2, outB = r2.y > h2;  // every Muller kernel returns 0 beyond h (kernels_impl.cuh:92,110,129,148)
+    // Wpressure_grad: kpress_grad * (r / rlen) * c, c = (h - rlen)^2
+    const f2 hm = splat2(ir) - len;
+    const f2 c = hm * hm;
+    V3x2 gs;
+    gs.x = splat2(P.kpress_grad) * div2(r.x, len) * c;
+    gs.y = splat2(P.kpress_grad) * div2(r.y, len) * c;
+    gs.z = splat2(P.kpress_grad) * div2(r.z, len) * c;
+    // Wviscosity_grad: kvisc_grad * r * c, c = -(3 rlen / kvisc_denum) + (2 / h2) - (h / (2 rlen rlen rlen))
+    const f2 t3 = splat2(3.0f) * len;
+    const f2 l3 = splat2(2.0f) * len * len * len;
+    const f2 cv = -div2(t3, splat2(P.kvisc_denum)) + splat2(2.0f / h2) - div2(splat2(ir), l3);
+    V3x2 gv = {splat2(P.kvisc_grad) * r.x * cv, splat2(P.kvisc_grad) * r.y * cv, splat2(P.kvisc_grad) * r.z * cv};
+    // Wdefault: kpoly * (h2 - r2)^3, the cube formed in double and rounded once
+    const f2 hr = splat2(h2) - r2;
+    f2 kern = splat2(P.kpoly) * pair2(cube_via_double<float>(hr.x), cube_via_double<float>(hr.y));
+    if (outA) { gs.x.x = 0.f; gs.y.x = 0.f; gs.z.x = 0.f; gv.x.x = 0.f; gv.y.x = 0.f; gv.z.x = 0.f; kern.x = 0.f; }
+    if (outB) { gs.x.y = 0.f; gs.y.y = 0.f; gs.z.y = 0.f; gv.x.y = 0.f; gv.y.y = 0.f; gv.z.y = 0.f; kern.y = 0.f; }
+    PairTerms2 T;
+    // fpres += m2 * (pres / rhoSqOwn + pOverRhoSqNb) * gradSpiky
+    const f2 sp = splat2(m2) * (splat2(own) + pair2(qa.prq, qb.prq));
+    T.pres.x = sp * gs.x; T.pres.y = sp * gs.y; T.pres.z = sp * gs.z;
+    // fvisc += mOverRhoNb * vij * (a / b), a = dot(rij, gradVisc), b = dot(rij, rij) + 0.01 (ir * ir)
+    const f2 a = dot2(r, gv);
+    const f2 b = d2 + splat2(0.01f * (ir * ir));
+    const f2 q = div2(a, b);
+    const f2 mr = pair2(qa.mrho, qb.mrho);
+    T.visc.x = mr * v.x * q; T.visc.y = mr * v.y * q; T.visc.z = mr * v.z * q;
+    if (SURF) {
+        // ai = 0 - (kappa / pm * pm * rij * (r2 > diameter2 ? kernel : wAtDiameter)), r2 = dot(rij, rij)
+        const f2 ks = pair2(d2.x > diameter2 ? kern.x : wAtDiameter, d2.y > diameter2 ? kern.y : wAtDiameter);
+        const f2 z = splat2(0.f);
+        T.surf.x = z - splat2(c0) * r.x * ks; T.surf.y = z - splat2(c0) * r.y * ks; T.surf.z = z - splat2(c0) * r.z * ks;
+    }
+    return T;
+}
+
 // ---- phase 2 of the forces (computeCellForces, sph_kernel_impl.cuh:442-604): hits → accumulators ----------
 template <typename R, int KSET, bool SURF, bool HAS_B, bool STRICT = false, bool PAIRS = false, bool BOUNDARY_BY_CELL = false>
 NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
@@ -662,6 +766,33 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                 }
         return A;
     }
+#if NRS_PACKED_HITS
+    if constexpr (!HAS_B && !STRICT && PAIRS && KSET == KS_MULLER && std::is_same<R, float>::value) {
+        // interior code, fluid hits only: two consecutive hits per iteration on packed fp32 (fluid_terms2_muller); the list heads of
+        // the NEXT iteration are requested before this iteration's gathers are used
+        const int nf = hc.nf;
+        const float own = pres / rhoSqOwn, c0 = kappa / pm * pm;
+        uint32_t e0 = nf > 0 ? lbase[0] : 0u, e1 = nf > 1 ? lbase[lstride] : e0;
+        for (int k = 0; k < nf; k += 2) {
+            const uint32_t j0 = e0 & HIT_INDEX, j1 = e1 & HIT_INDEX;
+            const bool two = k + 1 < nf;
+            const uint32_t n0 = k + 2 < nf ? lbase[(uint32_t)(k + 2) * lstride] : 0u;
+            const uint32_t n1 = k + 3 < nf ? lbase[(uint32_t)(k + 3) * lstride] : n0;
+            const PairTerms2 T = fluid_terms2_muller<SURF>(P, pos1, vel1, own, c0, wAtDiameter, diameter2, sPos[j0], sPos[j1], sVel[j0], sVel[j1],
+                                                           pairs[j0], pairs[j1]);
+            A.fpres = A.fpres + mk3<R>(T.pres.x.x, T.pres.y.x, T.pres.z.x);
+            A.fvisc = A.fvisc + mk3<R>(T.visc.x.x, T.visc.y.x, T.visc.z.x);
+            if (SURF) A.fsurf = A.fsurf + mk3<R>(T.surf.x.x, T.surf.y.x, T.surf.z.x);
+            if (two) {
+                A.fpres = A.fpres + mk3<R>(T.pres.x.y, T.pres.y.y, T.pres.z.y);
+                A.fvisc = A.fvisc + mk3<R>(T.visc.x.y, T.visc.y.y, T.visc.z.y);
+                if (SURF) A.fsurf = A.fsurf + mk3<R>(T.surf.x.y, T.surf.y.y, T.surf.z.y);
+            }
+            e0 = n0; e1 = n1;
+        }
+        return A;
+    }
+#endif
     HitMerge it(lbase, lstride, hc);
     uint32_t j, key;
     bool isB;
@@ -1007,8 +1138,9 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
 
 // DEFER: wall workgroups first, interior workgroups skip the particles flagged COUNTS_DEFERRED (see k_density_tiled); HAS_B is
 // false for the interior code
+// (the packed two-hit walk of the interior code needs 94 VGPRs: 5 waves per SIMD; the scalar walk is bounded for 7)
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? FORCES_LISTS_MIN_WAVES : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? ((NRS_PACKED_HITS && NRS_FORCE_PAIRS && KSET == KS_MULLER && !HAS_B) ? FORCES_PACKED_MIN_WAVES : FORCES_LISTS_MIN_WAVES) : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const typename Vec4T<R>::type *__restrict__ sVel,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,

@@ -9,6 +9,8 @@ from nereus_amd.params import default_params
 
 mode, arg = sys.argv[1], sys.argv[-1]
 p = default_params(0)
+if os.environ.get("NEREUS_ABL_DT"):   # time step of the run that produces the saved state (round 3: 2.5e-4, the bench's)
+    p["timestep"][0] = float(os.environ["NEREUS_ABL_DT"])
 sc = scene.dam_break(scene.CONFIGS["NS"], h=float(p["interactionRadius"][0]), kpoly=float(p["kpoly"][0]))
 n = len(sc["pos"])
 s = capi.Solver(p, n)
