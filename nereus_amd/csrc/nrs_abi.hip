@@ -129,7 +129,7 @@ struct nrs_ctx {
 extern "C" {
 
 const char *nrs_last_error(void) { return g_err.c_str(); }
-uint32_t nrs_version(void) { return (0u << 16) | 1u; }
+uint32_t nrs_version(void) { return (0u << 16) | 2u; } // 0.2: NRS_FLAG_STAGED_SCAN / NO_WALL_WORKGROUPS, nrs_slab_last_counts, asynchronous nrs_step
 int nrs_device_count(void)
 {
     int n = 0;
@@ -220,6 +220,7 @@ int nrs_step(nrs_ctx *ctx, int nsteps)
         // nothing in flight: refuse a call the context's state does not allow NOW, as a synchronous call would (mid-update after a
         // partial step, a host-driven IISPH step in progress, inconsistent state); single steps run right here
         { const int drc = ctx->drain(); if (drc != NRS_OK) return drc; }
+        NRSCHK(ctx->impl->settle());
         if (nsteps <= 1) return ctx->impl->step(nsteps, 0);
         NRSCHK(ctx->impl->step(0, 0));
     }
