@@ -455,3 +455,51 @@ def test_slab_rccl_cpp_driver_one_rank(tmp_path, hip_lib, solver):
         a, b = np.argsort(gv[:, 3], kind="stable"), np.argsort(rv[:, 3], kind="stable")
         assert np.array_equal(gv[a, 3], ids)
         assert rel_err(gp[a, :3], rp[b, :3]) <= 1e-5 and rel_err(gv[a, :3], rv[b, :3]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_slab_pack_defers_its_totals(hip_lib):
+    """include/nereus_hip.h: nrs_slab_pack(counts = NULL) queues the partition and returns; the stream totals are read back by
+    nrs_slab_unpack (together with the received headers) or by whichever call needs the particle count first — and a message-capacity
+    overflow is then reported there, not lost."""
+    import ctypes as C
+
+    sys.path.insert(0, ROOT)
+    from nereus_amd import capi, slab
+    from nereus_amd.params import default_params
+    from tests.common import rel_err
+
+    p, cuts, pos, vel, bi, vbi, info = slab.rank_scene((20, 16, 14), 0, 1, default_params(0))
+    n = len(pos)
+    s = capi.Solver(p, 2 * n)
+    s.set_particles(pos, vel)
+    s.set_boundaries(bi, vbi, update_grid=False)
+    s.slab_configure(slab.NO_CUT_LO, slab.NO_CUT_HI, 2)
+    # (a) open slab, no neighbours: pack without counts, the next call that needs n settles it
+    assert s.slab_pack(None, None, 4096, want_counts=False) is None
+    assert s.n == n and s.slab_last_counts() == [n, 0, 0, 0, 0, 0]
+    s.slab_unpack(None, None, 4096)
+    s.step(2)
+    r = capi.Solver(p, 2 * n)
+    r.set_particles(pos, vel)
+    r.set_boundaries(bi, vbi, update_grid=False)
+    r.step(2)
+    a, b = s.download(), r.download()
+    assert rel_err(np.sort(a[0][:, 0]), np.sort(b[0][:, 0])) <= 1e-5
+    # (b) a cut through the block and a message buffer far too small: the pack itself returns, the overflow surfaces at the next call
+    shim = C.CDLL(os.path.join(ROOT, "nereus_amd", "libnereus_refshim.so"))
+    shim.allocateArray.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    buf = C.c_void_p()
+    cap = 64
+    shim.allocateArray(C.byref(buf), s.message_bytes(cap))
+    t = capi.Solver(p, 2 * n)
+    t.set_particles(pos, vel)
+    t.set_boundaries(bi, vbi, update_grid=False)
+    cx = slab.cell_of(pos[:, 0], float(p["worldOrigin"][0][0]), float(p["cellSize"][0][0]))
+    t.slab_configure(slab.NO_CUT_LO, int(np.median(cx)), 2)      # everything right of the median cell has to leave to the right
+    assert t.slab_pack(None, buf, cap, want_counts=False) is None
+    with pytest.raises(capi.NereusError, match="capacity"):
+        t.slab_unpack(None, None, cap)
+    shim.freeArray.argtypes = [C.c_void_p]
+    t.close()
+    shim.freeArray(buf)
