@@ -204,6 +204,9 @@ static inline int device_f2i(SReal v)
     if (v <= (SReal)-2147483648.0) return (int)(-2147483647 - 1);
     return (int)v;
 }
+/* gridPos + offset as the devices form it: 32-bit two's-complement wrap-around (a saturated cell coordinate of a particle at +-inf plus one
+ * is signed overflow — undefined — in host C++; the hash masks the low bits either way) */
+static inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 static inline I3 calcGridPos(const SphSimParams &P, SVec3 p)
 {
     I3 g;
@@ -375,7 +378,7 @@ static inline SReal densityOf(const Grid &G, SUint slot, const SVec4 *sPos)
     for (int z = -1; z <= 1; z++)
         for (int y = -1; y <= 1; y++)
             for (int x = -1; x <= 1; x++) {
-                I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                 dens += cellDensity(G, nb, slot, p, sPos);
                 dens += cellDensityBoundary(G, nb, p);
             }
@@ -504,7 +507,7 @@ static void k_forces(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     cellForces(G, &fpres, &fvisc, &fsurf, &fbound, nb, slot, pos, vel, dens, pres, S.sPos.data(),
                                S.sDens.data(), S.sPres.data(), S.sVel.data());
                 }
@@ -603,7 +606,7 @@ static void k_displacementFactor(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     cellForces(G, &fpres, &fvisc, &fsurf, &fbound, nb, slot, pos1, vel1, dens, pres, S.sPos.data(),
                                S.sDens.data(), S.sPres.data(), S.sVel.data());
                 }
@@ -618,7 +621,7 @@ static void k_displacementFactor(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     df = df + dispCell(G, dens, nb, pos1, S.sPos.data(), slot);
                     db = db + dispCellBoundary(G, dens, nb, pos1);
                 }
@@ -738,7 +741,7 @@ static void k_advectionFactor(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     rho_advf += rhoAdvFluid(G, slot, pos1, velAdv1, S.sPos.data(), S.velAdv.data(), nb);
                     rho_advb += rhoAdvBoundary(G, pos1, vel1, nb);
                 }
@@ -749,7 +752,7 @@ static void k_advectionFactor(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     aii += aiiCell(G, dens, pos1, diif, diib, S.sPos.data(), nb, slot);
                     aii += aiiCellBoundary(G, dens, diif, diib, pos1, nb);
                 }
@@ -771,7 +774,7 @@ static void k_sumDijPj(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     SVec3 res = mk3(0, 0, 0);
                     const SUint h = calcGridHash(P, nb);
                     const SUint s = G.cellStart[h];
@@ -820,7 +823,7 @@ static void k_pressure(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     const SUint h = calcGridHash(P, nb);
                     const SUint s = G.cellStart[h];
                     if (s != EMPTY) {
@@ -884,7 +887,7 @@ static void k_pressureForce(Sim &S, const Grid &G)
         for (int z = -1; z <= 1; z++)
             for (int y = -1; y <= 1; y++)
                 for (int x = -1; x <= 1; x++) {
-                    I3 nb = {gp.x + x, gp.y + y, gp.z + z};
+                    I3 nb = {wadd(gp.x, x), wadd(gp.y, y), wadd(gp.z, z)};
                     const SUint h = calcGridHash(P, nb);
                     const SUint s = G.cellStart[h];
                     if (s != EMPTY) {
