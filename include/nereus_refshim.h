@@ -8,8 +8,9 @@
  * (it owns every array, it sequences the stages itself) can run stage by stage on an MI355X.  The fast path is the context API of
  * nereus_hip.h (device-resident state, fused launches, coherent re-sort); this layer exists for A/B-ing single stages.
  *
- * What the reference fixes at COMPILE time is fixed here too: SReal = float (DOUBLE_PRECISION=0), Muller kernels (KERNEL_SET=1),
- * USE_SURFACE_TENSION=1 — the reference's shipped build (CMakeLists.txt:25-28).
+ * What the reference fixes at COMPILE time is fixed per library here too: libnereus_refshim.so is SReal = float (DOUBLE_PRECISION=0),
+ * Muller kernels (KERNEL_SET=1), USE_SURFACE_TENSION=1 — the reference's shipped build (CMakeLists.txt:25-28); libnereus_refshim_f64.so,
+ * libnereus_refshim_monaghan.so and libnereus_refshim_f64_monaghan.so are the other three DOUBLE_PRECISION x KERNEL_SET combinations.
  *
  * What this layer does NOT provide: the CUDA runtime.  The reference's sph.cpp also calls cudaMalloc / cudaMemcpy / cudaMemset
  * directly (sph.cpp:141-185,233-284); a caller of this layer allocates with allocateArray (hipMalloc) or hands in any HIP device
@@ -38,10 +39,16 @@
 extern "C" {
 #endif
 
-typedef float SReal_f32;
+/* SReal as the reference's common/common.h:23-43 selects it: compile the CALLER with -DDOUBLE_PRECISION=1 and link
+ * libnereus_refshim_f64[_monaghan].so for the double build (KERNEL_SET=0: ..._monaghan) */
+#if defined(DOUBLE_PRECISION) && DOUBLE_PRECISION
+typedef double nrs_sreal;
+#else
+typedef float nrs_sreal;
+#endif
 typedef unsigned int SUint_t;
-typedef struct nrs_vec3_f32 { float x, y, z; } nrs_vec3_f32;       /* SVec3 = float3 */
-typedef struct nrs_vec4_f32 { float x, y, z, w; } nrs_vec4_f32;    /* SVec4 = float4 */
+typedef struct nrs_vec3 { nrs_sreal x, y, z; } nrs_vec3;       /* SVec3 */
+typedef struct nrs_vec4 { nrs_sreal x, y, z, w; } nrs_vec4;    /* SVec4 = float4 */
 
 /* sph.cuh:25-26, 28; sph_cuda.cu:94-110 */
 void allocateArray(void **devPtr, size_t size);
@@ -51,45 +58,45 @@ void threadSync(void);
 void copyArrayToDevice(void *device, const void *host, int offset, int size);
 void copyArrayFromDevice(void *host, const void *device, void **cuda_vbo_resource, int size);
 /* sph.cuh:40; sph_cuda.cu:183-187: the parameter block every later launch uses (the reference's __constant__ sph_params) */
-void setParameters(nrs_params_f32 *hostParams);
+void setParameters(void *hostParams); /* SphSimParams = nrs_params_f32 / nrs_params_f64 by DOUBLE_PRECISION */
 /* sph.cuh:50-54; sph_cuda.cu:211-225 (deltaTime is what integrate_functor uses; the reference passes params.timestep) */
-void integrateSystem(float *pos, float *vel, float *forces, float deltaTime, SUint_t numParticles);
+void integrateSystem(nrs_sreal *pos, nrs_sreal *vel, nrs_sreal *forces, nrs_sreal deltaTime, SUint_t numParticles);
 /* sph.cuh:59-62; sph_cuda.cu:230-246 */
-void calcHash(SUint_t *gridParticleHash, SUint_t *gridParticleIndex, float *pos, int numParticles);
+void calcHash(SUint_t *gridParticleHash, SUint_t *gridParticleIndex, nrs_sreal *pos, int numParticles);
 /* sph.cuh:160; sph_cuda.cu:58-63: ascending by key, stable (ties keep index order), as thrust::sort_by_key's radix sort */
 void sortParticles(SUint_t *dGridParticleHash, SUint_t *dGridParticleIndex, SUint_t numParticles);
 /* sph.cuh:67-77; sph_cuda.cu:251-293 (Q1: sortedPos / sortedVbi ARE filled) */
-void reorderDataAndFindCellStartDBoundary(SUint_t *cellStart, SUint_t *cellEnd, float *sortedPos, float *sortedVbi, SUint_t *gridParticleHash,
-                                          SUint_t *gridParticleIndex, float *oldPos, float *oldVbi, SUint_t numBoundaries, SUint_t numCells);
+void reorderDataAndFindCellStartDBoundary(SUint_t *cellStart, SUint_t *cellEnd, nrs_sreal *sortedPos, nrs_sreal *sortedVbi, SUint_t *gridParticleHash,
+                                          SUint_t *gridParticleIndex, nrs_sreal *oldPos, nrs_sreal *oldVbi, SUint_t numBoundaries, SUint_t numCells);
 /* sph.cuh:82-99; sph_cuda.cu:295-358: memsets cellStart, gathers pos / vel / pres (the other arrays are passed NULL by the
  * reference's own launcher and are ignored here as there) */
-void reorderDataAndFindCellStart(SUint_t *cellStart, SUint_t *cellEnd, float *sortedPos, float *sortedVel, float *sortedDens, float *sortedPres,
-                                 float *sortedForces, float *sortedCol, SUint_t *gridParticleHash, SUint_t *gridParticleIndex, float *oldPos,
-                                 float *oldVel, float *oldDens, float *oldPres, float *oldForces, float *oldCol, SUint_t numParticles,
+void reorderDataAndFindCellStart(SUint_t *cellStart, SUint_t *cellEnd, nrs_sreal *sortedPos, nrs_sreal *sortedVel, nrs_sreal *sortedDens, nrs_sreal *sortedPres,
+                                 nrs_sreal *sortedForces, nrs_sreal *sortedCol, SUint_t *gridParticleHash, SUint_t *gridParticleIndex, nrs_sreal *oldPos,
+                                 nrs_sreal *oldVel, nrs_sreal *oldDens, nrs_sreal *oldPres, nrs_sreal *oldForces, nrs_sreal *oldCol, SUint_t numParticles,
                                  SUint_t numCells);
 /* sph.cuh:104-108; sph_cuda.cu:461-505 */
-nrs_vec3_f32 BBMin(float *sortedBoundaryPos, SUint_t numBoundaries);
-nrs_vec3_f32 BBMax(float *sortedBoundaryPos, SUint_t numBoundaries);
+nrs_vec3 BBMin(nrs_sreal *sortedBoundaryPos, SUint_t numBoundaries);
+nrs_vec3 BBMax(nrs_sreal *sortedBoundaryPos, SUint_t numBoundaries);
 /* sph.cuh:113-130; sph_cuda.cu:366-456: the density / Tait-pressure kernel AND the force kernel, as the reference's launcher */
-void computeDensityPressure(float *sortedPos, float *sortedVel, float *sortedDens, float *sortedPres, float *sortedForces, float *sortedCol,
-                            float *sortedBoundaryPos, float *sortedBoundaryVbi, SUint_t *gridParticleIndex, SUint_t *cellStart, SUint_t *cellEnd,
+void computeDensityPressure(nrs_sreal *sortedPos, nrs_sreal *sortedVel, nrs_sreal *sortedDens, nrs_sreal *sortedPres, nrs_sreal *sortedForces, nrs_sreal *sortedCol,
+                            nrs_sreal *sortedBoundaryPos, nrs_sreal *sortedBoundaryVbi, SUint_t *gridParticleIndex, SUint_t *cellStart, SUint_t *cellEnd,
                             SUint_t *gridBoundaryIndex, SUint_t *cellBoundaryStart, SUint_t *cellBoundaryEnd, SUint_t numParticles,
                             SUint_t numCells, SUint_t numBoundaries);
 /* sph.cuh:155-158; sph_cuda.cu:32-53 (maxVelocity returns the velocity vector of largest length) */
-float maxDensity(float *dDensities, SUint_t numParticles);
-nrs_vec4_f32 maxVelocity(float *dVelocities, SUint_t numParticles);
+nrs_sreal maxDensity(nrs_sreal *dDensities, SUint_t numParticles);
+nrs_vec4 maxVelocity(nrs_sreal *dVelocities, SUint_t numParticles);
 /* IISPH: sph.cuh:168-207; sph_cuda.cu:513-899 */
-void predictAdvection(float *sortedPos, float *sortedVel, float *sortedDens, float *sortedPres, float *sortedForces, float *sortedCol,
-                      SUint_t *cellStart, SUint_t *cellEnd, SUint_t *gridParticleIndex, float *sortedBoundaryPos, float *sortedBoundaryVbi,
-                      SUint_t *cellBoundaryStart, SUint_t *cellBoundaryEnd, SUint_t *gridBoundaryIndex, float *sortedDensAdv,
-                      float *sortedDensCorr, float *sortedP_l, float *sortedPreviousP, float *sortedAii, float *sortedVelAdv,
-                      float *sortedForcesAdv, float *sortedForcesP, float *sortedDiiFluid, float *sortedDiiBoundary, float *sortedSumDij,
-                      float *sortedNormal, SUint_t numParticles, SUint_t numBoundaries, SUint_t numCells);
-void pressureSolve(float *sortedPos, float *sortedVel, float *sortedDens, float *sortedPres, float *sortedForces, float *sortedCol,
-                   SUint_t *cellStart, SUint_t *cellEnd, SUint_t *gridParticleIndex, float *sortedBoundaryPos, float *sortedBoundaryVbi,
-                   SUint_t *cellBoundaryStart, SUint_t *cellBoundaryEnd, SUint_t *gridBoundaryIndex, float *sortedDensAdv, float *sortedDensCorr,
-                   float *sortedP_l, float *sortedPreviousP, float *sortedAii, float *sortedVelAdv, float *sortedForcesAdv, float *sortedForcesP,
-                   float *sortedDiiFluid, float *sortedDiiBoundary, float *sortedSumDij, float *sortedNormal, SUint_t numParticles,
+void predictAdvection(nrs_sreal *sortedPos, nrs_sreal *sortedVel, nrs_sreal *sortedDens, nrs_sreal *sortedPres, nrs_sreal *sortedForces, nrs_sreal *sortedCol,
+                      SUint_t *cellStart, SUint_t *cellEnd, SUint_t *gridParticleIndex, nrs_sreal *sortedBoundaryPos, nrs_sreal *sortedBoundaryVbi,
+                      SUint_t *cellBoundaryStart, SUint_t *cellBoundaryEnd, SUint_t *gridBoundaryIndex, nrs_sreal *sortedDensAdv,
+                      nrs_sreal *sortedDensCorr, nrs_sreal *sortedP_l, nrs_sreal *sortedPreviousP, nrs_sreal *sortedAii, nrs_sreal *sortedVelAdv,
+                      nrs_sreal *sortedForcesAdv, nrs_sreal *sortedForcesP, nrs_sreal *sortedDiiFluid, nrs_sreal *sortedDiiBoundary, nrs_sreal *sortedSumDij,
+                      nrs_sreal *sortedNormal, SUint_t numParticles, SUint_t numBoundaries, SUint_t numCells);
+void pressureSolve(nrs_sreal *sortedPos, nrs_sreal *sortedVel, nrs_sreal *sortedDens, nrs_sreal *sortedPres, nrs_sreal *sortedForces, nrs_sreal *sortedCol,
+                   SUint_t *cellStart, SUint_t *cellEnd, SUint_t *gridParticleIndex, nrs_sreal *sortedBoundaryPos, nrs_sreal *sortedBoundaryVbi,
+                   SUint_t *cellBoundaryStart, SUint_t *cellBoundaryEnd, SUint_t *gridBoundaryIndex, nrs_sreal *sortedDensAdv, nrs_sreal *sortedDensCorr,
+                   nrs_sreal *sortedP_l, nrs_sreal *sortedPreviousP, nrs_sreal *sortedAii, nrs_sreal *sortedVelAdv, nrs_sreal *sortedForcesAdv, nrs_sreal *sortedForcesP,
+                   nrs_sreal *sortedDiiFluid, nrs_sreal *sortedDiiBoundary, nrs_sreal *sortedSumDij, nrs_sreal *sortedNormal, SUint_t numParticles,
                    SUint_t numBoundaries, SUint_t numCells);
 /* not in sph.cuh: solver iterations of the last pressureSolve (the `l` of sph_cuda.cu:736), for tests */
 SUint_t nrs_refshim_last_iterations(void);

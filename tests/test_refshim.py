@@ -18,23 +18,28 @@ HEADER = os.path.join(ROOT, "include", "nereus_refshim.h")
 
 def declared():
     txt = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    return sorted(set(re.findall(r"^\s*(?:void|float|SUint_t|nrs_vec3_f32|nrs_vec4_f32)\s+\**(\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:void|nrs_sreal|SUint_t|nrs_vec3|nrs_vec4)\s+\**(\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_refshim_exports_every_declared_symbol():
     names = declared()
     assert len(names) >= 19 and "calcHash" in names and "pressureSolve" in names and "computeDensityPressure" in names
-    lib = C.CDLL(LIB)
-    for n in names:
-        assert hasattr(lib, n), n
+    for suffix in ("", "_f64", "_monaghan", "_f64_monaghan"):   # one library per DOUBLE_PRECISION x KERNEL_SET of the reference
+        lib = C.CDLL(LIB.replace(".so", suffix + ".so"))
+        for n in names:
+            assert hasattr(lib, n), (suffix, n)
 
 
-class V3(C.Structure):
-    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+def vec_types(double):
+    ct = C.c_double if double else C.c_float
 
+    class V3(C.Structure):
+        _fields_ = [("x", ct), ("y", ct), ("z", ct)]
 
-class V4(C.Structure):
-    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+    class V4(C.Structure):
+        _fields_ = [("x", ct), ("y", ct), ("z", ct), ("w", ct)]
+
+    return ct, V3, V4
 
 
 class Dev:
@@ -63,15 +68,16 @@ class Dev:
             self.p = None
 
 
-def load():
-    lib = C.CDLL(LIB)
+def load(double=False, kset=1):
+    lib = C.CDLL(LIB.replace(".so", ("_f64" if double else "") + ("_monaghan" if kset == 0 else "") + ".so"))
+    ct, V3, V4 = vec_types(double)
     vp = C.c_void_p
     lib.allocateArray.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.freeArray.argtypes = [vp]
     lib.copyArrayToDevice.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.copyArrayFromDevice.argtypes = [vp, vp, vp, C.c_int]
     lib.setParameters.argtypes = [vp]
-    lib.integrateSystem.argtypes = [vp, vp, vp, C.c_float, C.c_uint]
+    lib.integrateSystem.argtypes = [vp, vp, vp, ct, C.c_uint]
     lib.calcHash.argtypes = [vp, vp, vp, C.c_int]
     lib.sortParticles.argtypes = [vp, vp, C.c_uint]
     lib.reorderDataAndFindCellStartDBoundary.argtypes = [vp] * 8 + [C.c_uint, C.c_uint]
@@ -84,7 +90,7 @@ def load():
     lib.BBMax.argtypes = [vp, C.c_uint]
     lib.BBMax.restype = V3
     lib.maxDensity.argtypes = [vp, C.c_uint]
-    lib.maxDensity.restype = C.c_float
+    lib.maxDensity.restype = ct
     lib.maxVelocity.argtypes = [vp, C.c_uint]
     lib.maxVelocity.restype = V4
     lib.nrs_refshim_last_iterations.restype = C.c_uint
@@ -94,15 +100,16 @@ def load():
 class RefCaller:
     """What the reference's sph.cpp / iisph.cpp do with the launcher layer, written against the same entry points."""
 
-    def __init__(self, lib, params, pos, vel, bi, vbi, iisph=False):
+    def __init__(self, lib, params, pos, vel, bi, vbi, iisph=False, double=False):
         self.lib, self.iisph = lib, iisph
+        self.real = np.float64 if double else np.float32
         self.p = np.array(params).copy()
         self.n, self.nb = len(pos), 0 if bi is None else len(bi)
         self.cells = int(self.p["numCells"][0])
-        n, V, S, U = self.n, 16, 4, 4
+        n, V, S, U = self.n, (32 if double else 16), (8 if double else 4), 4
         d = lambda nbytes, host=None: Dev(lib, nbytes, host)
-        self.pos, self.vel = d(n * V, pos.astype(np.float32)), d(n * V, vel.astype(np.float32))
-        self.pres = d(n * S, np.zeros(n, np.float32))
+        self.pos, self.vel = d(n * V, pos.astype(self.real)), d(n * V, vel.astype(self.real))
+        self.pres = d(n * S, np.zeros(n, self.real))
         self.sPos, self.sVel, self.sDens, self.sPres, self.sForces = d(n * V), d(n * V), d(n * S), d(n * S), d(n * V)
         self.hash, self.index = d(n * U), d(n * U)
         self.cs, self.ce = d(self.cells * U), d(self.cells * U)
@@ -112,7 +119,7 @@ class RefCaller:
         self.sbPos, self.sbVbi, self.bHash, self.bIndex = d(nb * V), d(nb * S), d(nb * U), d(nb * U)
         lib.setParameters(self.p.ctypes.data_as(C.c_void_p))
         if self.nb:   # SPH::updateGpuBoundaries (sph.cpp:391-432)
-            self.bPos.put(bi.astype(np.float32)); self.bVbi.put(vbi.astype(np.float32))
+            self.bPos.put(bi.astype(self.real)); self.bVbi.put(vbi.astype(self.real))
             lib.calcHash(self.bHash.p, self.bIndex.p, self.bPos.p, self.nb)
             lib.sortParticles(self.bHash.p, self.bIndex.p, self.nb)
             lib.reorderDataAndFindCellStartDBoundary(self.bcs.p, self.bce.p, self.sbPos.p, self.sbVbi.p, self.bHash.p, self.bIndex.p, self.bPos.p,
@@ -121,7 +128,7 @@ class RefCaller:
             self.bcs.put(np.full(self.cells, 0xFFFFFFFF, np.uint32))
         if iisph:
             self.extra = {k: d(n * (V if k in ("velAdv", "forcesAdv", "forcesP", "diiF", "diiB", "sumDij", "normal") else S),
-                               np.zeros(n * (4 if k in ("velAdv", "forcesAdv", "forcesP", "diiF", "diiB", "sumDij", "normal") else 1), np.float32))
+                               np.zeros(n * (4 if k in ("velAdv", "forcesAdv", "forcesP", "diiF", "diiB", "sumDij", "normal") else 1), self.real))
                           for k in ("densAdv", "densCorr", "P_l", "prevP", "aii", "velAdv", "forcesAdv", "forcesP", "diiF", "diiB", "sumDij", "normal")}
 
     def update(self):
@@ -145,40 +152,42 @@ class RefCaller:
             lib.pressureSolve(*args)                                              # :207-212
             self.pres_swap()
         # the reference copies sorted -> host -> device (sph.cpp:283-284, 233-234); here device to device through the host arrays
-        self.host_pos, self.host_vel = self.sPos.get(np.float32, (n, 4)), self.sVel.get(np.float32, (n, 4))
+        self.host_pos, self.host_vel = self.sPos.get(self.real, (n, 4)), self.sVel.get(self.real, (n, 4))
         self.pos.put(self.host_pos); self.vel.put(self.host_vel)
 
     def pres_swap(self):   # iisph.cpp:216: m_pressure <- sorted pressures, the next step's warm start
-        self.pres.put(self.sPres.get(np.float32, (self.n,)))
+        self.pres.put(self.sPres.get(self.real, (self.n,)))
 
 
 @pytest.mark.gpu
-def test_refshim_sesph_chain_equals_context_and_oracle(hip_lib):
+@pytest.mark.parametrize("double,kset", [(False, 1), (True, 0)], ids=["f32-muller", "f64-monaghan"])
+def test_refshim_sesph_chain_equals_context_and_oracle(hip_lib, double, kset):
     from nereus_amd import capi
     from tests.common import rel_err, small_dam_break
     from tests.oracle_lib import SESPH, Oracle
 
-    p, sc = small_dam_break((16, 14, 12))
-    o = Oracle(p, solver=SESPH)
+    real = np.float64 if double else np.float32
+    p, sc = small_dam_break((16, 14, 12), double=double, kernel_set=kset)
+    o = Oracle(p, double, kset, SESPH)
     o.set_particles(sc["pos"], sc["vel"])
     o.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
-    lib = load()
-    c = RefCaller(lib, o.params, sc["pos"], sc["vel"], sc["bi"], sc["vbi"])
-    s = capi.Solver(p, len(sc["pos"]), reference_order=True, flags=capi.FLAG_FULL_SORT | capi.FLAG_NO_FUSION)
+    lib = load(double, kset)
+    c = RefCaller(lib, o.params, sc["pos"], sc["vel"], sc["bi"], sc["vbi"], double=double)
+    s = capi.Solver(p, len(sc["pos"]), double=double, kernel_set=kset, reference_order=True, flags=capi.FLAG_FULL_SORT | capi.FLAG_NO_FUSION)
     s.set_particles(sc["pos"], sc["vel"])
     s.set_boundaries(sc["bi"], sc["vbi"], update_grid=True)
     # the boundary tables the caller built through the shim == the context's
     np.testing.assert_array_equal(c.bHash.get(np.uint32, (c.nb,)), s.get("bhash"))
     np.testing.assert_array_equal(c.bIndex.get(np.uint32, (c.nb,)), s.get("bindex"))
-    np.testing.assert_array_equal(c.sbPos.get(np.float32, (c.nb, 4))[:, :3], s.get("bSorted")[:, :3])
-    np.testing.assert_array_equal(c.sbVbi.get(np.float32, (c.nb,)), s.get("bSorted")[:, 3])
+    np.testing.assert_array_equal(c.sbPos.get(real, (c.nb, 4))[:, :3], s.get("bSorted")[:, :3])
+    np.testing.assert_array_equal(c.sbVbi.get(real, (c.nb,)), s.get("bSorted")[:, 3])
     mn, mx = lib.BBMin(c.sbPos.p, c.nb), lib.BBMax(c.sbPos.p, c.nb)           # sph.cpp:313-337 computes the grid from these
     assert (mn.x, mn.y, mn.z) == tuple(sc["bi"][:, :3].min(0)) and (mx.x, mx.y, mx.z) == tuple(sc["bi"][:, :3].max(0))
     for _ in range(3):
         c.update(); s.step(1); o.step(1)
         np.testing.assert_array_equal(c.hash.get(np.uint32, (c.n,)), o.get("hash"))
         np.testing.assert_array_equal(c.index.get(np.uint32, (c.n,)), o.get("index"))
-        np.testing.assert_array_equal(c.sDens.get(np.float32, (c.n,)), s.get("dens"))
+        np.testing.assert_array_equal(c.sDens.get(real, (c.n,)), s.get("dens"))
         gp, gv = s.download()
         np.testing.assert_array_equal(c.host_pos, gp)       # the same kernels behind both interfaces: bit for bit
         np.testing.assert_array_equal(c.host_vel, gv)
@@ -206,4 +215,4 @@ def test_refshim_iisph_chain_equals_oracle(hip_lib):
         np.testing.assert_array_equal(c.index.get(np.uint32, (c.n,)), o.get("index"))
         assert rel_err(c.host_pos[:, :3], o.get("pos")[:, :3]) <= 1e-5
         assert rel_err(c.host_vel[:, :3], o.get("vel")[:, :3]) <= 1e-5
-        assert rel_err(c.sPres.get(np.float32, (c.n,)), o.get("pressure")) <= 1e-4
+        assert rel_err(c.sPres.get(np.float32, (c.n,)), o.get("pressure")) <= 1e-4   # (the IISPH test runs the fp32 Muller shim)
