@@ -97,7 +97,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
     QuantCfg qc;
     uint32_t qT = 0;
     bool qOk = false;
-    DevBuf pairBuf; // (p / rho^2, m / rho) per sorted slot: density kernel -> force kernel of the same step (HitBuffer::pairs)
+    DevBuf gatherPos, gatherVel; // (x, y, z, p / rho^2) and (vx, vy, vz, m / rho) per sorted slot: density kernel -> force kernel of the same step (HitBuffer)
     DevBuf qpos; // two words per sorted slot (+ 4 slots of padding), written by the reorder kernels
     // hit lists are built (and the kernels that consume them used) only when the scan that builds them can run
     bool lists_ok() const { return hitBuf.p != nullptr && (NRS_COMPACT_SCAN == 0 || (qOk && qpos.p != nullptr)); }
@@ -286,7 +286,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         DevBuf *all[] = {&posA, &posB, &velA, &velB, &presA, &presB, &dens, &forces, &hashA, &hashB, &indexA, &indexB,
                          &inv, &sortTmp, &cellStart, &cellEnd, &bCellStart, &bCellEnd, &bSorted, &bHash, &bIndex,
                          &bHashAlt, &bIndexAlt, &densAdv, &densCorr, &P_l, &P_l2, &aii, &velAdv, &forcesAdv, &forcesP,
-                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &qpos, &pairBuf, &fastQ, &nearBits, &wallList, &wallMask, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
+                         &diiF, &diiB, &sumDij, &diiSum, &redPartial, &redOut, &errWord, &hitBuf, &hitCounts, &qpos, &gatherPos, &gatherVel, &fastQ, &nearBits, &wallList, &wallMask, &wallTile, &wallTileOffset, &wallGroupTotal, &wallGroupPrefix, &wallScalars, &ghostPos, &ghostVel, &slabCounts, &slabTotals,
                          &rsMovers, &rsMoversAlt, &rsStayers, &rsMerged, &rsTileMovers, &rsTileOffset, &rsGroupTotal, &rsGroupPrefix, &rsScalars, &rsPrevPacked,
                          &rsTileDead, &rsTileDeadOffset, &rsGroupDeadTotal, &rsGroupDeadPrefix, &slabFlags};
         for (DevBuf *b : all) b->release();
@@ -346,7 +346,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
             NRSCHK(hitCounts.alloc((size_t)cap * 4));
             if (NRS_COMPACT_SCAN) NRSCHK(qpos.alloc(((size_t)cap + 4) * QP_BYTES));
-            if (NRS_FORCE_PAIRS && !iisph()) NRSCHK(pairBuf.alloc((size_t)cap * 2 * sizeof(R)));
+            if (NRS_FORCE_PAIRS && !iisph()) { NRSCHK(gatherPos.alloc((size_t)cap * sizeof(T4))); NRSCHK(gatherVel.alloc((size_t)cap * sizeof(T4))); }
             if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
                 NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
@@ -813,7 +813,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slabOn) { G.actLo = slab.lo - 1; G.actHi = slab.hi + 1; } // density is also needed one cell beyond the cuts
         // the density kernel's hit lists are handed to the force kernel when both run in this call
         HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
-        if (NRS_FORCE_PAIRS) hb.pairs = pairBuf.p;
+        if (NRS_FORCE_PAIRS) { hb.gpos = gatherPos.p; hb.gvel = gatherVel.p; hb.svel = velB.p; }
         if constexpr (std::is_same<R, float>::value) { if (fastArith() && fastQ.p && !stagedScan()) hb.fast = fastQ.as<FastPair>(); }
         const bool share = !refOrder() && lists_ok() && stop != NRS_STAGE_DENSITY;
         NRSCHK(ev_begin(NRS_STAGE_DENSITY));

@@ -341,11 +341,7 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
             }
             dens[i] = d;
             if (pres) pres[i] = pr;
-            if (SHARE && !FAST && hb.pairs && active) { // what the list-driven force kernel gathers (HitBuffer::pairs, k_density_tiled)
-                PrePair<R> q;
-                q.prq = pr / (d * d); q.mrho = P.particleMass / d;
-                reinterpret_cast<PrePair<R> *>(hb.pairs)[i] = q;
-            }
+            if (SHARE && !FAST && hb.gpos && active) publish_gather_records<R>(P, hb, i, p, own_sorted_velocity<R>(hb, i), d, pr); // what the list-driven force kernel gathers (HitBuffer, k_density_tiled)
             if (FAST && fq) {
                 const float inv = active ? 1.0f / d : 0.f;
                 FastPair z; z.pr = pr * inv * inv; z.invRho = inv;
@@ -380,11 +376,9 @@ __global__ __launch_bounds__(STG_WAVE, STG_MIN_WAVES) void k_density_staged(Para
     }
     dens[i] = d;
     if (pres) pres[i] = pr;
-    if (SHARE && !FAST && hb.pairs) { // (p / rho^2, m / rho) with the operands and IEEE divisions of the force loop, as k_density_tiled leaves
-        PrePair<float> q;             // them: round 2 made the list-driven force kernel gather these, and this launch did not write them —
-        q.prq = pr / (d * d); q.mrho = P.particleMass / d; // found by the first test that ran the staged launch (round 3)
-        reinterpret_cast<PrePair<float> *>(hb.pairs)[i] = q;
-    }
+    // the gather records of the list-driven force kernel, as k_density_tiled leaves them: round 2 made that kernel gather per-slot pairs, and this
+    // launch did not write them — found by the first test that ran the staged launch (round 3)
+    if (SHARE && !FAST && hb.gpos) publish_gather_records<float>(P, hb, i, p, own_sorted_velocity<float>(hb, i), d, pr);
     if (FAST && fq) {
         const float inv = 1.0f / d;
         FastPair z; z.pr = pr * inv * inv; z.invRho = inv;

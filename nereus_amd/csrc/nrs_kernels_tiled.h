@@ -155,7 +155,7 @@ template <typename R> struct Sweep {
                     const V3<R> d = p - xyz<R>(c[u]);
                     const bool hit = (q < nT) & (j != self) & (dot(d, d) < tF);
                     if (hit) {
-                        uint32_t tag = tag0 + ((m1 != CELL_EMPTY) & (j >= m1) ? 1u : 0u);
+                        uint32_t tag = tag0 + (((m1 != CELL_EMPTY) & (j >= m1)) ? 1u : 0u);
                         if ((m2 != CELL_EMPTY) & (j >= m2)) tag = tag0 + 2u;
                         if (nf + nb < HIT_CAP) lst[nf][tid] = j | (tag << HIT_TAG_SHIFT); else over = true;
                         ++nf;
@@ -497,7 +497,12 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
 // — 3 * row (from the scan) + the cell's place in the row, from calcGridPos's own expression on the candidate's exact x — and is
 // written back to the front of the thread's LDS column (w <= k): what is published afterwards is exactly the list scan() would
 // have produced, and the sums are formed in the same order (one partial sum per cell).
-template <typename R, int KSET, bool STRICT>
+// INRANGE (fp32, Muller kernels; the caller's wave-uniform vote, density_inrange_ok): the cell-tag division and the square root of a kept
+// entry run as the bare steps of nrs_math.h "operands in range".  Guards: the cell size in [2^-20, 2^20] and the owner at least four and
+// at most 2^30 cells from the grid origin in x — a kept entry is less than h < 1.99 cells from its owner, so its numerator x - origin is at
+// least two cells in magnitude and the quotient lies in [2, 2^31]; the square root's argument is below tKeep, and an entry below 2^-96
+// (coincident particles) takes sqrtf.
+template <typename R, int KSET, bool STRICT, bool INRANGE = false>
 NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::type *__restrict__ sPos, V3<R> p, uint32_t (*lst)[BLOCK],
                                 int &nf, float tKeep, uint32_t self)
 {
@@ -505,6 +510,8 @@ NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::typ
     const R ir = P.interactionRadius, kp = P.kpoly, pm = P.particleMass;
     const uint32_t mx = P.gridSize[0] - 1;
     const int gxi = (int)floor((p.x - P.worldOrigin[0]) / P.cellSize[0]);
+    float yCell = 0.f;
+    if constexpr (INRANGE) yCell = rcp_refined((float)P.cellSize[0]);
     R d = (R)0.0;
     d += pm * W_dens<R, KSET>(mk3<R>(0, 0, 0), ir, kp);
     R part = (R)0.0;
@@ -523,23 +530,48 @@ NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::typ
         for (int u = 0; u < QP_WALK; ++u) {
             const V3<R> r = p - q[u];
             const uint32_t j = e[u] & HIT_INDEX;
-            if ((k0 + u < nf) && (dot(r, r) < tKeep) && (STRICT || j != self)) { // (STRICT: the wide IISPH list keeps the particle itself)
+            const float d2 = dot(r, r);
+            if ((k0 + u < nf) && (d2 < tKeep) && (STRICT || j != self)) { // (STRICT: the wide IISPH list keeps the particle itself)
 #if defined(NRS_ABL_NODIV) // timing ablation: row tags only (summation order within a row is then not the reference's)
                 const uint32_t tag = (e[u] >> HIT_TAG_SHIFT);
 #else
-                const int gxj = (int)floor((q[u].x - P.worldOrigin[0]) / P.cellSize[0]);
+                int gxj;
+                if constexpr (INRANGE) gxj = (int)floor(div_steps((float)(q[u].x - P.worldOrigin[0]), (float)P.cellSize[0], yCell));
+                else gxj = (int)floor((q[u].x - P.worldOrigin[0]) / P.cellSize[0]);
                 const uint32_t tag = (e[u] >> HIT_TAG_SHIFT) + (((uint32_t)(gxj - gxi) + 1u) & mx);
 #endif
                 lst[min(w, HIT_CAP - 1)][tid] = j | (tag << HIT_TAG_SHIFT);
                 ++w;
                 if (tag != prevTag) { d += part; part = (R)0.0; prevTag = tag; }
-                if (!STRICT || ((j != self) && (length(r) < ir))) part += (pm * W_dens<R, KSET>(r, ir, kp));
+                if constexpr (INRANGE) {
+                    // Wdefault (kernels_impl.cuh:85-98) on length(r) = sqrt(dot(r, r)), the square root without its scaling
+                    const float len = d2 >= 0x1p-96f ? sqrt_inrange(d2) : sqrt_rn(d2);
+                    if (!STRICT || ((j != self) && (len < ir))) {
+                        const float r2 = len * len, h2 = ir * ir;
+                        part += (pm * (r2 > h2 ? 0.0f : kp * cube_via_double<float>(h2 - r2)));
+                    }
+                } else {
+                    if (!STRICT || ((j != self) && (length(r) < ir))) part += (pm * W_dens<R, KSET>(r, ir, kp));
+                }
             }
         }
     }
     d += part;
     nf = w;
     return d;
+}
+// the vote behind INRANGE: true for the whole wave or for none of its lanes
+template <typename R> NRS_DEV bool density_inrange_ok(const Params<R> &P, V3<R> p)
+{
+    if constexpr (!std::is_same<R, float>::value) return false;
+    else {
+#if NRS_INRANGE_DIV
+        const float cs = P.cellSize[0], n = fabsf(p.x - P.worldOrigin[0]);
+        return __all(cs >= 0x1p-20f && cs <= 0x1p20f && n >= 4.0f * cs && n <= 0x1p30f * cs) != 0;
+#else
+        return false;
+#endif
+    }
 }
 
 // The three boundary terms of one (fluid particle, boundary particle) pair, computeCellForces sph_kernel_impl.cuh:566-602:
@@ -625,18 +657,77 @@ NRS_DEV f2 div2(f2 a, f2 b)
     return pair2(a.x / b.x, a.y / b.y);
 #endif
 }
+// ---- the force walk's divisions and square roots for operands in range (nrs_math.h "operands in range") ----------------------------------
+// Five of the six divisions of a hit and its square root run as the bare arithmetic steps of the compiler's own expansions, two hits at a
+// time on packed fp32, behind three guards:
+//   launch constants (wave-uniform): 2^-10 <= h <= 2^10, 2^-40 <= |kvisc_denum| <= 2^40;
+//   owner (wave-uniform vote): every coordinate |x| >= 2^-66 — then a component of rij = pos1 - pos2 is either +0 or at least 2^-90 in
+//     magnitude (a non-zero difference of two floats is a multiple of the smaller ulp; -0 needs a zero owner coordinate);
+//   hit: 2^-16 h^2 <= dot(rij, rij) < 2 h^2 (one unsigned range test on the bits: NaN, inf and negative patterns fail it).
+// With them: rij.c / rlen has |n| <= rlen (1 + 2^-22), rlen in [2^-18, 2^11]; 3 rlen / kvisc_denum lies in [2^-58, 2^53];
+// h / (2 rlen^3) has its denominator in [2^-53, 2^34] and lies in [2^-44, 2^63] — all inside v_div_scale's pass-through region.  A wave whose
+// vote fails walks with the compiler's divisions as before; a lane whose hit fails the range test repeats its walk that way after the loop.
+// rij.c = +0: v_div_fixup returns +0, the steps return +0 too (0 * y = +0, fma(-d, +0, +0) = +0, fma(+0, y, +0) = +0).
+// a / b of the viscosity term keeps the compiler's division (the range of a = dot(rij, gradVisc) does not follow from the guards).
+// Measured (tools/ab_flowing.sh, tools/busy_flowing.sh): vector instructions per wave of the force launch 2280 -> 1710 in the bench's window
+// and VALU busy 81 % -> 60 % — and the launch takes the same 0.88 ms there, because in that window it is bound by the L1 (0.57 line
+// accesses per cycle and CU, TA 71-77 % busy: 34 distinct lines per gather instruction); at rest, six hits per particle, 0.382 -> 0.351 ms.
+NRS_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+NRS_DEV f2 rcp_refined2(f2 d) // steps 1-3: the reciprocal every quotient by d is built from
+{
+    const f2 r = pair2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+    return fma2(fma2(-d, r, splat2(1.0f)), r, r);
+}
+NRS_DEV f2 div_steps2(f2 n, f2 d, f2 y) // steps 4-8
+{
+    const f2 nd = -d;
+    const f2 q0 = n * y;
+    const f2 q1 = fma2(fma2(nd, q0, n), y, q0);
+    return fma2(fma2(nd, q1, n), y, q1);
+}
+NRS_DEV f2 sqrt_inrange2(f2 x)
+{
+    const float sa = __builtin_amdgcn_sqrtf(x.x), sb = __builtin_amdgcn_sqrtf(x.y);
+    const f2 s = pair2(sa, sb);
+    const f2 dn = pair2(__uint_as_float(__float_as_uint(sa) - 1u), __uint_as_float(__float_as_uint(sb) - 1u));
+    const f2 up = pair2(__uint_as_float(__float_as_uint(sa) + 1u), __uint_as_float(__float_as_uint(sb) + 1u));
+    const f2 vp = fma2(-dn, s, x), vs = fma2(-up, s, x);
+    f2 o = s;
+    o.x = 0.f >= vp.x ? dn.x : o.x; o.x = 0.f < vs.x ? up.x : o.x;
+    o.y = 0.f >= vp.y ? dn.y : o.y; o.y = 0.f < vs.y ? up.y : o.y;
+    return o;
+}
+struct InRange { float yVisc; uint32_t loBits, spanBits; bool constantsOk; };
+NRS_DEV InRange in_range_setup(const Params<float> &P)
+{
+    InRange G;
+    const float h = P.interactionRadius, h2 = h * h, kvd = fabsf(P.kvisc_denum);
+    G.constantsOk = h >= 0x1p-10f && h <= 0x1p10f && kvd >= 0x1p-40f && kvd <= 0x1p40f;
+    G.yVisc = rcp_refined(P.kvisc_denum);
+    G.loBits = __float_as_uint(h2 * 0x1p-16f);
+    G.spanBits = __float_as_uint(h2 * 2.0f) - G.loBits;
+    return G;
+}
+
 struct PairTerms2 { V3x2 pres, visc, surf; };
 // the three pair terms of computeCellForces (sph_kernel_impl.cuh:520-548) for hits (a, b) of one owner; `own` = pres / (dens * dens)
-// of the owner, c0 = kappa / pm * pm, both formed once per owner with the scalar code's operations
-template <bool SURF>
+// of the owner, c0 = kappa / pm * pm, both formed once per owner with the scalar code's operations.  INRANGE: the forms above; `bad` is
+// set when one of the two hits is outside their range (the caller then repeats the owner's walk with INRANGE = false).
+template <bool SURF, bool INRANGE>
 NRS_DEV PairTerms2 fluid_terms2_muller(const Params<float> &P, V3<float> pos1, V3<float> vel1, float own, float c0, float wAtDiameter, float diameter2,
-                                       float4 pa, float4 pb, float4 va, float4 vb, PrePair<float> qa, PrePair<float> qb)
+                                       float4 pa, float4 pb, float4 va, float4 vb, PrePair<float> qa, PrePair<float> qb, const InRange &G, bool &bad)
 {
     const float ir = P.interactionRadius, m2 = P.particleMass;
     const V3x2 r = {splat2(pos1.x) - pair2(pa.x, pb.x), splat2(pos1.y) - pair2(pa.y, pb.y), splat2(pos1.z) - pair2(pa.z, pb.z)};
     const V3x2 v = {splat2(vel1.x) - pair2(va.x, vb.x), splat2(vel1.y) - pair2(va.y, vb.y), splat2(vel1.z) - pair2(va.z, vb.z)};
     const f2 d2 = dot2(r, r);                       // dot(rij, rij)
-    const f2 len = pair2(sqrt_rn(d2.x), sqrt_rn(d2.y)); // length(rij)
+    f2 len;                                         // length(rij)
+    if (INRANGE) {
+        bad = bad || (__float_as_uint(d2.x) - G.loBits >= G.spanBits) || (__float_as_uint(d2.y) - G.loBits >= G.spanBits);
+        len = sqrt_inrange2(d2);
+    } else {
+        len = pair2(sqrt_rn(d2.x), sqrt_rn(d2.y));
+    }
     const f2 r2 = len * len;
     const float h2 = ir * ir;
     const bool outA = r2.x > h2, outB = r2.y > h2;  // every Muller kernel returns 0 beyond h (kernels_impl.cuh:92,110,129,148)
@@ -644,13 +735,22 @@ NRS_DEV PairTerms2 fluid_terms2_muller(const Params<float> &P, V3<float> pos1, V
     const f2 hm = splat2(ir) - len;
     const f2 c = hm * hm;
     V3x2 gs;
-    gs.x = splat2(P.kpress_grad) * div2(r.x, len) * c;
-    gs.y = splat2(P.kpress_grad) * div2(r.y, len) * c;
-    gs.z = splat2(P.kpress_grad) * div2(r.z, len) * c;
     // Wviscosity_grad: kvisc_grad * r * c, c = -(3 rlen / kvisc_denum) + (2 / h2) - (h / (2 rlen rlen rlen))
     const f2 t3 = splat2(3.0f) * len;
     const f2 l3 = splat2(2.0f) * len * len * len;
-    const f2 cv = -div2(t3, splat2(P.kvisc_denum)) + splat2(2.0f / h2) - div2(splat2(ir), l3);
+    f2 cv;
+    if (INRANGE) {
+        const f2 y = rcp_refined2(len);
+        gs.x = splat2(P.kpress_grad) * div_steps2(r.x, len, y) * c;
+        gs.y = splat2(P.kpress_grad) * div_steps2(r.y, len, y) * c;
+        gs.z = splat2(P.kpress_grad) * div_steps2(r.z, len, y) * c;
+        cv = -div_steps2(t3, splat2(P.kvisc_denum), splat2(G.yVisc)) + splat2(2.0f / h2) - div_steps2(splat2(ir), l3, rcp_refined2(l3));
+    } else {
+        gs.x = splat2(P.kpress_grad) * div2(r.x, len) * c;
+        gs.y = splat2(P.kpress_grad) * div2(r.y, len) * c;
+        gs.z = splat2(P.kpress_grad) * div2(r.z, len) * c;
+        cv = -div2(t3, splat2(P.kvisc_denum)) + splat2(2.0f / h2) - div2(splat2(ir), l3);
+    }
     V3x2 gv = {splat2(P.kvisc_grad) * r.x * cv, splat2(P.kvisc_grad) * r.y * cv, splat2(P.kvisc_grad) * r.z * cv};
     // Wdefault: kpoly * (h2 - r2)^3, the cube formed in double and rounded once
     const f2 hr = splat2(h2) - r2;
@@ -683,7 +783,8 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const typename Vec4T<R>::type *__restrict__ sVel, const R *__restrict__ sDens,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
                                      const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu,
-                                     const R *pre = nullptr, const PrePair<R> *__restrict__ pairs = nullptr)
+                                     const R *pre = nullptr, const typename Vec4T<R>::type *__restrict__ gpos = nullptr,
+                                     const typename Vec4T<R>::type *__restrict__ gvel = nullptr)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -704,19 +805,23 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         A.fvisc = A.fvisc - T.visc;
     };
     auto fluidHit = [&](uint32_t j) {
-        const V3<R> rij = pos1 - xyz<R>(sPos[j]);
-        if (STRICT && ((j == self) || !(length(rij) < ir))) return; // the loop's own tests (:494,:505)
+        V3<R> rij, vij;
         R pOverRhoSqNb, mOverRhoNb; // pNb / (rhoNb * rhoNb), m2 / rhoNb
-        if (PAIRS) {
-            const PrePair<R> q = pairs[j];
-            pOverRhoSqNb = q.prq; mOverRhoNb = q.mrho;
+        if (PAIRS) { // the neighbour's two gather records (HitBuffer)
+            const typename Vec4T<R>::type a = gpos[j], b = gvel[j];
+            rij = pos1 - xyz<R>(a);
+            if (STRICT && ((j == self) || !(length(rij) < ir))) return; // the loop's own tests (:494,:505)
+            vij = vel1 - xyz<R>(b);
+            pOverRhoSqNb = a.w; mOverRhoNb = b.w;
         } else {
+            rij = pos1 - xyz<R>(sPos[j]);
+            if (STRICT && ((j == self) || !(length(rij) < ir))) return;
             const R rhoNb = sDens[j];
             const R pNb = sPres[j];
             const R rhoSqNb = rhoNb * rhoNb;
             pOverRhoSqNb = pNb / rhoSqNb; mOverRhoNb = m2 / rhoNb;
+            vij = vel1 - xyz<R>(sVel[j]);
         }
-        const V3<R> vij = vel1 - xyz<R>(sVel[j]);
         V3<R> gradSpiky, gradVisc;
         R kernel;
         if (KSET == KS_MONAGHAN) {
@@ -772,24 +877,54 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         // the NEXT iteration are requested before this iteration's gathers are used
         const int nf = hc.nf;
         const float own = pres / rhoSqOwn, c0 = kappa / pm * pm;
-        uint32_t e0 = nf > 0 ? lbase[0] : 0u, e1 = nf > 1 ? lbase[lstride] : e0;
-        for (int k = 0; k < nf; k += 2) {
-            const uint32_t j0 = e0 & HIT_INDEX, j1 = e1 & HIT_INDEX;
-            const bool two = k + 1 < nf;
-            const uint32_t n0 = k + 2 < nf ? lbase[(uint32_t)(k + 2) * lstride] : 0u;
-            const uint32_t n1 = k + 3 < nf ? lbase[(uint32_t)(k + 3) * lstride] : n0;
-            const PairTerms2 T = fluid_terms2_muller<SURF>(P, pos1, vel1, own, c0, wAtDiameter, diameter2, sPos[j0], sPos[j1], sVel[j0], sVel[j1],
-                                                           pairs[j0], pairs[j1]);
-            A.fpres = A.fpres + mk3<R>(T.pres.x.x, T.pres.y.x, T.pres.z.x);
-            A.fvisc = A.fvisc + mk3<R>(T.visc.x.x, T.visc.y.x, T.visc.z.x);
-            if (SURF) A.fsurf = A.fsurf + mk3<R>(T.surf.x.x, T.surf.y.x, T.surf.z.x);
-            if (two) {
-                A.fpres = A.fpres + mk3<R>(T.pres.x.y, T.pres.y.y, T.pres.z.y);
-                A.fvisc = A.fvisc + mk3<R>(T.visc.x.y, T.visc.y.y, T.visc.z.y);
-                if (SURF) A.fsurf = A.fsurf + mk3<R>(T.surf.x.y, T.surf.y.y, T.surf.z.y);
+        auto walk = [&](auto inRange, const InRange &IG, bool &bad) {
+            ForceAcc<R> S;
+            S.fpres = S.fvisc = S.fsurf = S.fbound = mk3<R>(0, 0, 0);
+            uint32_t e0 = nf > 0 ? lbase[0] : 0u, e1 = nf > 1 ? lbase[lstride] : e0;
+            for (int k = 0; k < nf; k += 2) {
+#if defined(NRS_ABL_FORCE_COALESCED) // timing ablation: the gathers of a wave hit consecutive slots (what a staged walk could reach at best)
+                const uint32_t j0 = (blockIdx.x * BLOCK + threadIdx.x + (uint32_t)k * 3u) % G.nSorted, j1 = (j0 + 1u) % G.nSorted;
+#elif defined(NRS_ABL_FORCE_QUAD) // timing ablation: the four lanes of a quad gather the hits of the quad's first owner (16 distinct owners per gather)
+                const uint32_t *lq = lbase - (threadIdx.x & 3u);
+                const uint32_t j0 = (lq[(uint32_t)k * lstride] & HIT_INDEX) % G.nSorted, j1 = (lq[(uint32_t)min(k + 1, HIT_CAP - 1) * lstride] & HIT_INDEX) % G.nSorted;
+#else
+                const uint32_t j0 = e0 & HIT_INDEX, j1 = e1 & HIT_INDEX;
+#endif
+                const bool two = k + 1 < nf;
+                const uint32_t n0 = k + 2 < nf ? lbase[(uint32_t)(k + 2) * lstride] : 0u;
+                const uint32_t n1 = k + 3 < nf ? lbase[(uint32_t)(k + 3) * lstride] : n0;
+#if defined(NRS_ABL_FORCE_NOVEL) // timing ablation: one gather per hit
+                const float4 pa = gpos[j0], pb = gpos[j1], va = pa, vb = pb;
+#else
+                const float4 pa = gpos[j0], pb = gpos[j1], va = gvel[j0], vb = gvel[j1];
+#endif
+                const PairTerms2 T = fluid_terms2_muller<SURF, decltype(inRange)::value>(P, pos1, vel1, own, c0, wAtDiameter, diameter2, pa, pb, va, vb,
+                                                                                        PrePair<float>{pa.w, va.w}, PrePair<float>{pb.w, vb.w}, IG, bad);
+                S.fpres = S.fpres + mk3<R>(T.pres.x.x, T.pres.y.x, T.pres.z.x);
+                S.fvisc = S.fvisc + mk3<R>(T.visc.x.x, T.visc.y.x, T.visc.z.x);
+                if (SURF) S.fsurf = S.fsurf + mk3<R>(T.surf.x.x, T.surf.y.x, T.surf.z.x);
+                if (two) {
+                    S.fpres = S.fpres + mk3<R>(T.pres.x.y, T.pres.y.y, T.pres.z.y);
+                    S.fvisc = S.fvisc + mk3<R>(T.visc.x.y, T.visc.y.y, T.visc.z.y);
+                    if (SURF) S.fsurf = S.fsurf + mk3<R>(T.surf.x.y, T.surf.y.y, T.surf.z.y);
+                }
+                e0 = n0; e1 = n1;
             }
-            e0 = n0; e1 = n1;
+            return S;
+        };
+#if NRS_INRANGE_DIV
+        const InRange IG = in_range_setup(P);
+        const bool ownerOk = fminf(fminf(fabsf(pos1.x), fabsf(pos1.y)), fabsf(pos1.z)) >= 0x1p-66f;
+        bool again = true;
+        if (IG.constantsOk && __all(ownerOk)) { // (a vote of the lanes that walk: the branch is wave-uniform)
+            again = false;
+            A = walk(std::true_type{}, IG, again);
         }
+        if (again) A = walk(std::false_type{}, IG, again);
+#else
+        bool unused = false;
+        A = walk(std::false_type{}, InRange{}, unused);
+#endif
         return A;
     }
 #endif
@@ -826,13 +961,36 @@ NRS_DEV uint32_t xcd_tile(uint32_t b, uint32_t nb)
 // Hit lists shared between the two gathers of a step: the density kernel scans once, uses the hits, and (when
 // `hb.hits` is set) leaves them in global memory for the force kernel, which then needs no scan and no LDS.
 // hits[k * stride + i] is particle i's k-th list slot (k-major ⇒ coalesced), counts[i] = nf | nb << 8 | over << 16.
-// pairs (SESPH): per sorted slot (p / rho^2, m / rho), formed ONCE by the density kernel with the operands and the divisions the
-// force loop would use for that neighbour (computeCellForces, sph_kernel_impl.cuh:531,541) — two IEEE divisions less per hit there,
-// one 8-byte gather instead of two 4-byte ones; bit-identical by construction.  null = the force loop divides itself.
+// gather records (SESPH): per sorted slot (x, y, z, p / rho^2) and (vx, vy, vz, m / rho) — what the force walk needs of a NEIGHBOUR, in two
+// 16-byte records written by the density kernel.  The two quotients are formed ONCE per particle with the operands and the divisions
+// the force loop would use for that neighbour (computeCellForces, sph_kernel_impl.cuh:531,541: two IEEE divisions less per hit there,
+// bit-identical by construction), and they ride in the w lanes of copies of the sorted position and velocity, so that a hit costs TWO
+// gathers (2 x global_load_dwordx4) instead of three (position, velocity, 8-byte pair).  The walk is bound by the L1 — the lanes of a wave
+// sit in different rows of the neighbourhood, so every gather instruction touches ~34 distinct lines whatever it loads — and the third
+// gather was a third of its line accesses: force launch 0.889 -> 0.758 ms in the bench's window (tools/ab_flowing.sh), for 0.02-0.03 ms
+// more in the density launch (one coalesced read of the velocities, 32 instead of 8 bytes stored per particle).  The sorted arrays
+// themselves keep their w lanes (the caller's payload).  gpos == nullptr: the force loop divides itself and gathers sPos / sVel / dens / pres.
 // fast (NRS_FLAG_FAST_ARITH): per sorted slot (p * (1/rho)^2, 1/rho) with a hardware reciprocal, for the tolerance-mode force kernel
 // (nrs_kernels_staged.h, k_forces_fast); the density itself stays exact.
 struct FastPair { float pr, invRho; };
-struct HitBuffer { uint32_t *hits; uint32_t *counts; uint32_t stride; void *pairs = nullptr; FastPair *fast = nullptr; };
+struct HitBuffer {
+    uint32_t *hits; uint32_t *counts; uint32_t stride;
+    void *gpos = nullptr, *gvel = nullptr; // the gather records (Vec4T<R>::type[capacity] each)
+    const void *svel = nullptr;            // sorted velocities of this step (the density kernel copies xyz into gvel)
+    FastPair *fast = nullptr;
+};
+// (p / rho^2, m / rho) of one particle into its gather records
+template <typename R> NRS_DEV typename Vec4T<R>::type own_sorted_velocity(const HitBuffer &hb, uint32_t i)
+{
+    return reinterpret_cast<const typename Vec4T<R>::type *>(hb.svel)[i];
+}
+template <typename R>
+NRS_DEV void publish_gather_records(const Params<R> &P, const HitBuffer &hb, uint32_t i, V3<R> p, typename Vec4T<R>::type v, R d, R pr)
+{
+    typedef typename Vec4T<R>::type T4;
+    reinterpret_cast<T4 *>(hb.gpos)[i] = mk4<R>(p, pr / (d * d));
+    reinterpret_cast<T4 *>(hb.gvel)[i] = mk4<R>(xyz<R>(v), P.particleMass / d);
+}
 NRS_DEV uint32_t pack_counts(HitCounts hc)
 {
     return (uint32_t)hc.nf | ((uint32_t)hc.nb << 8) | (hc.over ? 1u << 16 : 0u) | (hc.anyB ? 1u << 17 : 0u);
@@ -940,7 +1098,10 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
 #else
         if (hc.over) d = density_of<R, KSET, HAS_B>(P, G, sPos, i); // list overflow / far owner: reference-order path
         else {
-            d = density_from_superset<R, KSET, WIDE>(P, sPos, p, lst, hc.nf, WIDE ? thr.r2LeH2 : thr.lenLtIr, i);
+            constexpr bool CAN = KSET == KS_MULLER && std::is_same<R, float>::value;
+            const float tKeep = WIDE ? thr.r2LeH2 : thr.lenLtIr;
+            if (CAN && density_inrange_ok<R>(P, p)) d = density_from_superset<R, KSET, WIDE, CAN>(P, sPos, p, lst, hc.nf, tKeep, i); // (a vote: wave-uniform)
+            else d = density_from_superset<R, KSET, WIDE>(P, sPos, p, lst, hc.nf, tKeep, i);
             if (hc.nf > HIT_CAP) { hc.over = true; d = density_of<R, KSET, HAS_B>(P, G, sPos, i); } // (only when the list held HIT_CAP + 1 exact hits)
         }
 #endif
@@ -953,12 +1114,8 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
     if (pres) {
         const R pr = tait_pressure<R>(P, d);
         pres[i] = pr;
-        if (SHARE && hb.pairs) {
-            PrePair<R> q;
-            q.prq = pr / (d * d);
-            q.mrho = P.particleMass / d;
-            reinterpret_cast<PrePair<R> *>(hb.pairs)[i] = q;
-        }
+        // (the own velocity is requested HERE: asked for before the walk it costs 8 spilled registers at the 80-VGPR bound, 0.608 against 0.561 ms at rest)
+        if (SHARE && hb.gpos) publish_gather_records<R>(P, hb, i, p, own_sorted_velocity<R>(hb, i), d, pr);
         if (SHARE && hb.fast) {
             const float inv = __builtin_amdgcn_rcpf((float)d);
             FastPair z;
@@ -1130,7 +1287,8 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
         if (hc.over) A = gather_forces<R, KSET, SURF, HAS_B>(P, G, i, pos1, vel1, dens, pres, sPos, sVel, sDens, sPres);
         else // (the context hands out lists only together with the pairs array of the same density launch)
             A = forces_from_hits<R, KSET, SURF, HAS_B, false, NRS_FORCE_PAIRS != 0, (HAS_B && KSET == KS_MONAGHAN)>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride,
-                                                                                     hc, 0xffffffffu, nullptr, reinterpret_cast<const PrePair<R> *>(hb.pairs));
+                                                                                     hc, 0xffffffffu, nullptr, reinterpret_cast<const typename Vec4T<R>::type *>(hb.gpos),
+                                                                                     reinterpret_cast<const typename Vec4T<R>::type *>(hb.gvel));
         f = sesph_total_force<R>(P, A, dens);
     }
     forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);

@@ -40,6 +40,47 @@ template <typename R> NRS_DEV float dot(V3<R> a, V3<R> b) { return (float)(a.x *
 NRS_DEV float sqrt_rn(float x) { return sqrtf(x); }
 template <typename R> NRS_DEV float length(V3<R> v) { return sqrt_rn(dot(v, v)); }
 
+// ---- divisions and square roots for operands in range --------------------------------------------------------------------------------
+// The compiler expands a correctly rounded fp32 division into v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup
+// (AMDGPU LowerFDIV32; the ISA of `a / b` on gfx950 is exactly that, 11 instructions) and sqrtf into a scaling select, v_sqrt, two integer
+// neighbours, two residual fmas, two selects, the unscaling and a class test (15).  The scaling exists for operands near the ends of the
+// exponent range: v_div_scale returns its operand UNCHANGED (and clears the flag v_div_fmas reads, which then is a plain fma) when numerator
+// and denominator are non-zero, the denominator and its reciprocal are normal, the numerator is not tiny, the quotient is not denormal and
+// the exponents are less than 96 apart; v_div_fixup then only re-applies the quotient's sign.  For such operands the eight arithmetic steps
+// in between ARE the division, bit for bit — nothing is approximated, the scaling is simply not needed — and divisions by the same
+// denominator share the first three steps (for a launch constant they are formed once per thread).  Likewise sqrtf without its scaling for
+// 2^-96 <= x < inf.
+// The region the forms are used in (every use states the guard that puts its operands there, and what runs when the guard fails — the plain
+// `/` and sqrtf):  numerator +0, or 2^-90 <= |n| <= 2^90 with 2^-90 <= |d| <= 2^90 and 2^-104 < |n / d| < 2^96.
+// Why 2^-90 and not the ISA manual's "biased exponent above 23" (2^-103): the residual n - d q of a quotient step is a multiple of
+// 2^(e_n - 47); it is a float — and the step exact — only while that is at least 2^-149.  tools/check_div2.hip found the case: for d = 2e-4
+// the numerators +-1.34756e-31 (biased exponent 24) are a last-bit tie that the bare steps round the other way.  The same tool compares the
+// forms with `/` and sqrtf on the device over the region: all 2^32 numerator patterns for twelve denominators, 2^32 random pairs, and every
+// float in [2^-96, inf) for the square root — 0 differences.
+#ifndef NRS_INRANGE_DIV
+#define NRS_INRANGE_DIV 1 // 0: every division and square root as the compiler expands it
+#endif
+NRS_DEV float rcp_refined(float d) // steps 1-3: the reciprocal every quotient by d is built from
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+NRS_DEV float div_steps(float n, float d, float y) // steps 4-8, y = rcp_refined(d)
+{
+    const float q0 = n * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), y, q1);
+}
+NRS_DEV float sqrt_inrange(float x) // 2^-96 <= x < inf
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
+    float o = 0.f >= vp ? dn : s;
+    o = 0.f < vs ? up : o;
+    return o;
+}
+
 // x^3 the way g++ evaluates pow(SReal,int): in double, rounded once to SReal (kernels_impl.cuh:95)
 template <typename R> NRS_DEV R cube_via_double(R x) { double d = (double)x; return (R)(d * d * d); }
 // powf(x,2) (kernels_impl.cuh:113): float square, also in fp64 builds
@@ -243,7 +284,7 @@ template <typename R> NRS_DEV bool quant_far(const QuantCfg &q, V3<R> p)
 {
     float tx, ty, tz;
     quantize_t<R>(q, p, tx, ty, tz);
-    return !((fabsf(tx) < QP_FAR) & (fabsf(ty) < QP_FAR) & (fabsf(tz) < QP_FAR));
+    return !((fabsf(tx) < QP_FAR) && (fabsf(ty) < QP_FAR) && (fabsf(tz) < QP_FAR));
 }
 template <typename R> NRS_DEV qword_t quantize_pos(const QuantCfg &q, V3<R> p)
 {

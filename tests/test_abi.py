@@ -42,3 +42,18 @@ def test_no_silent_cpu_fallback():
     with pytest.raises(capi.NereusError) as e:
         capi.Solver(p, capacity=16)
     assert "-5" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_makefiles_can_build_every_library_from_nothing():
+    """`make -n -B` (dry run, everything out of date) must print a link line for each library the package loads: a rule that gets lost
+    shows up here and not only on a fresh checkout (the .so files are not in the history)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = {"nereus_amd/csrc": ["../libnereus_hip.so", "../libnereus_refshim.so", "../libnereus_refshim_f64.so",
+                                "../libnereus_refshim_monaghan.so", "../libnereus_refshim_f64_monaghan.so"],
+            "nereus_amd/host": ["libnereus_host.so"], "oracle": ["libnereus_oracle"]}
+    for d, outs in want.items():
+        r = subprocess.run(["make", "-n", "-B", "-C", os.path.join(root, d)], capture_output=True, text=True)
+        assert r.returncode == 0, (d, r.stderr[-400:])
+        for o in outs:
+            assert any(("-o " + o) in line or ("-o ../" + o) in line or (o in line and " -o " in line) for line in r.stdout.splitlines()), (d, o)

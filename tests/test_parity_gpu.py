@@ -514,6 +514,67 @@ def test_compact_scan_guards(hip_lib):
         s.close()
 
 
+def test_in_range_division_guards(hip_lib):
+    """The force walk and the density walk run most divisions and the square root of a hit as the bare arithmetic steps of the compiler's own
+    expansions (nrs_math.h "operands in range") behind guards; this drives every guard into its way out and asks for the reference-order
+    kernels' bits: owners with a coordinate of exactly +0 / -0 (the wave's vote fails: compiler divisions for the whole wave), owners and
+    neighbours with coordinates of 1e-30 and in the denormal range (differences below 2^-100), pairs closer than h / 256 and exactly
+    coincident pairs (the lane repeats its walk; rij / |rij| is then NaN as in the reference), and a cloud within four cells of the grid
+    origin in x (the density walk's cell-tag division)."""
+    base = Oracle.default_params(SESPH)
+    h = float(base["interactionRadius"][0])
+    rng = np.random.default_rng(77)
+
+    def cloud(centre, n, spread):
+        a = np.ones((n, 4), np.float32)
+        a[:, :3] = (np.asarray(centre) + rng.uniform(-spread * h, spread * h, (n, 3))).astype(np.float32)
+        return a
+
+    cases = []
+    z = cloud([0.0, 0.0, 0.0], 3000, 4.0)
+    z[0:40, 0] = 0.0; z[40:80, 1] = -0.0; z[80:120, 2] = 0.0; z[120:140, :3] = 0.0   # (the last 20 are coincident at the origin)
+    cases.append(("zero coordinates", z))
+    t = cloud([0.0, 0.0, 0.0], 3000, 4.0)
+    t[0:30, 0] = 1e-30; t[30:60, 0] = 2e-30; t[60:90, 0] = -1e-38; t[90:120, 0] = 1e-42; t[120:150, 1] = 3e-33
+    t[150:180, 0] = 1.4e-20; t[180:210, 0] = 2.0e-20; t[210:240, 0] = 1.4e-20 * (1 + 2.0 ** -22)   # (just above the owner guard's 2^-66)
+    t[0:240, 2] = np.repeat(rng.uniform(-h, h, 24).astype(np.float32), 10)                 # (so that they are neighbours of each other)
+    t[0:240, 1] = np.where((np.arange(240) < 120) | (np.arange(240) >= 150), np.tile(rng.uniform(-0.3 * h, 0.3 * h, 10).astype(np.float32), 24), t[0:240, 1])
+    cases.append(("tiny coordinates", t))
+    c = cloud([0.31, -0.22, 0.4], 3000, 4.0)
+    c[1000:1100, :3] = c[0:100, :3] + np.float32(1e-4 * h)
+    c[1100:1200, :3] = c[100:200, :3] * np.float32(1 + 2e-7)
+    c[1200:1300, :3] = c[200:300, :3]
+    cases.append(("close and coincident pairs", c))
+    cases.append(("next to the grid origin", cloud([-1.1 + 3.0 * h, 0.1, -0.2], 3000, 2.9)))
+    for name, pos in cases:
+        vel = np.zeros_like(pos)
+        vel[:, :3] = rng.uniform(-0.5, 0.5, (len(pos), 3)).astype(np.float32)
+        outs = []
+        for ref in (False, True):
+            s = capi.Solver(base, len(pos), reference_order=ref)
+            s.set_particles(pos, vel)
+            s.set_boundaries(None, None, update_grid=True)
+            s.step_partial(capi.STAGE_FORCES)
+            outs.append([s.get("hash"), s.get("index"), s.get("dens"), s.get("pres"), s.get("forces")])
+            s.set_particles(pos, vel)
+            s.step(3)
+            outs[-1] += list(s.download())
+            s.close()
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b, err_msg=name)    # (NaN == NaN here)
+        o = Oracle(base, False, 1, SESPH)
+        o.set_particles(pos, vel)
+        o.set_boundaries(None, None, update_grid=True)
+        o.step(1, stop=STOP_FORCES)
+        np.testing.assert_array_equal(outs[0][0], o.get("hash"), err_msg=name)
+        np.testing.assert_array_equal(outs[0][1], o.get("index"), err_msg=name)
+        od, of = o.get("dens"), o.get("forces")[:, :3]
+        np.testing.assert_array_equal(outs[0][2], od, err_msg=name)
+        fin = np.isfinite(of).all(1)
+        np.testing.assert_array_equal(np.isfinite(outs[0][4][:, :3]).all(1), fin, err_msg=name)
+        assert rel_err(outs[0][4][:, :3][fin], of[fin]) <= 10 * TOL_STAGE, name
+
+
 def test_iisph_stages_and_steps(hip_lib):
     p, pos, vel = compressed_block()
     o, s = make_pair(p, pos, vel, solver=IISPH)

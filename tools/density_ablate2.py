@@ -32,3 +32,5 @@ else:
         ts.append((t["density"][0], t["forces"][0]))
     print("%-28s %-6s density %.3f ms   forces %.3f ms" % (os.path.basename(os.environ.get("NEREUS_HIP_LIB", "main")), os.path.basename(arg)[:6],
                                                            min(a for a, b in ts), min(b for a, b in ts)))
+    if os.environ.get("NEREUS_ABL_ALL"):
+        print("   per evaluation (density, forces) ms:", " ".join("(%.3f, %.3f)" % t for t in ts))
