@@ -59,6 +59,11 @@ struct CutThresholds { float lenLtIr, r2LeH2; };
 #ifndef FORCES_PACKED_MIN_WAVES
 #define FORCES_PACKED_MIN_WAVES 5
 #endif
+// the force launch of a PARTIAL step (forces array out, no integration; tests and diagnostics): its register allocation spills ten dwords
+// into the hit loop at the 96-VGPR bound where the fused launch spills none (0.99 against 0.79 ms) — bounded for four waves instead
+#ifndef FORCES_PACKED_MIN_WAVES_UNFUSED
+#define FORCES_PACKED_MIN_WAVES_UNFUSED 4
+#endif
 // value of `v` in lane `srcLane` (wave-uniform lane number), for every lane
 NRS_DEV float bcast_lane(float v, int srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane)); }
 NRS_DEV double bcast_lane(double v, int srcLane)
@@ -497,11 +502,13 @@ NRS_DEV R density_from_hits(const Params<R> &P, const GridView<R> &G, const type
 // — 3 * row (from the scan) + the cell's place in the row, from calcGridPos's own expression on the candidate's exact x — and is
 // written back to the front of the thread's LDS column (w <= k): what is published afterwards is exactly the list scan() would
 // have produced, and the sums are formed in the same order (one partial sum per cell).
-// INRANGE (fp32, Muller kernels; the caller's wave-uniform vote, density_inrange_ok): the cell-tag division and the square root of a kept
-// entry run as the bare steps of nrs_math.h "operands in range".  Guards: the cell size in [2^-20, 2^20] and the owner at least four and
-// at most 2^30 cells from the grid origin in x — a kept entry is less than h < 1.99 cells from its owner, so its numerator x - origin is at
-// least two cells in magnitude and the quotient lies in [2, 2^31]; the square root's argument is below tKeep, and an entry below 2^-96
-// (coincident particles) takes sqrtf.
+// INRANGE (fp32, Muller kernels; the caller's wave-uniform decision, density_inrange_ok): the cell-tag division (x - origin) / cellSize and the
+// square root of a kept entry run as the bare steps of nrs_math.h "operands in range".  Guards: the cell size in [2^-20, 2^10], and the
+// numerator x - origin either +0 or at least 2^-90 — which holds for every particle when the grid origin itself is at least 2^-60 in
+// magnitude (a non-zero difference of two floats is a multiple of the smaller ulp), and otherwise for the kept entries of an owner that is at
+// least four cells from the origin (a kept entry is less than h < 1.99 cells from its owner); owners are at most 4096 cells from the origin
+// (Sweep::scan_compact), so the quotient stays below 2^13.  The square root's argument is below tKeep; an entry below 2^-96 (coincident
+// particles) takes sqrtf.
 template <typename R, int KSET, bool STRICT, bool INRANGE = false>
 NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::type *__restrict__ sPos, V3<R> p, uint32_t (*lst)[BLOCK],
                                 int &nf, float tKeep, uint32_t self)
@@ -560,14 +567,16 @@ NRS_DEV R density_from_superset(const Params<R> &P, const typename Vec4T<R>::typ
     nf = w;
     return d;
 }
-// the vote behind INRANGE: true for the whole wave or for none of its lanes
+// the decision behind INRANGE: true for the whole wave or for none of its lanes (launch constants, else a vote)
 template <typename R> NRS_DEV bool density_inrange_ok(const Params<R> &P, V3<R> p)
 {
     if constexpr (!std::is_same<R, float>::value) return false;
     else {
 #if NRS_INRANGE_DIV
-        const float cs = P.cellSize[0], n = fabsf(p.x - P.worldOrigin[0]);
-        return __all(cs >= 0x1p-20f && cs <= 0x1p20f && n >= 4.0f * cs && n <= 0x1p30f * cs) != 0;
+        const float cs = P.cellSize[0], wo = fabsf(P.worldOrigin[0]);
+        if (!(cs >= 0x1p-20f && cs <= 0x1p10f && wo <= 0x1p60f)) return false;
+        if (wo >= 0x1p-60f) return true;
+        return __all(fabsf(p.x - P.worldOrigin[0]) >= 4.0f * cs) != 0;
 #else
         return false;
 #endif
@@ -718,8 +727,15 @@ NRS_DEV PairTerms2 fluid_terms2_muller(const Params<float> &P, V3<float> pos1, V
                                        float4 pa, float4 pb, float4 va, float4 vb, PrePair<float> qa, PrePair<float> qb, const InRange &G, bool &bad)
 {
     const float ir = P.interactionRadius, m2 = P.particleMass;
-    const V3x2 r = {splat2(pos1.x) - pair2(pa.x, pb.x), splat2(pos1.y) - pair2(pa.y, pb.y), splat2(pos1.z) - pair2(pa.z, pb.z)};
-    const V3x2 v = {splat2(vel1.x) - pair2(va.x, vb.x), splat2(vel1.y) - pair2(va.y, vb.y), splat2(vel1.z) - pair2(va.z, vb.z)};
+    // The twelve differences are scalar subtractions, and stay so (the empty asm takes them as twelve scalars): as packed subtractions —
+    // written so, or put together by the SLP vectoriser — they need the owner's six coordinates splat into register pairs for the whole
+    // loop, which costs the fused launch a register spilled INTO the loop (0.87 -> 0.80 ms in the bench's window, 0.44 -> 0.39 at rest).
+    float rxa = pos1.x - pa.x, rxb = pos1.x - pb.x, rya = pos1.y - pa.y, ryb = pos1.y - pb.y, rza = pos1.z - pa.z, rzb = pos1.z - pb.z;
+    float vxa = vel1.x - va.x, vxb = vel1.x - vb.x, vya = vel1.y - va.y, vyb = vel1.y - vb.y, vza = vel1.z - va.z, vzb = vel1.z - vb.z;
+    asm volatile("" : "+v"(rxa), "+v"(rxb), "+v"(rya), "+v"(ryb), "+v"(rza), "+v"(rzb));
+    asm volatile("" : "+v"(vxa), "+v"(vxb), "+v"(vya), "+v"(vyb), "+v"(vza), "+v"(vzb));
+    const V3x2 r = {pair2(rxa, rxb), pair2(rya, ryb), pair2(rza, rzb)};
+    const V3x2 v = {pair2(vxa, vxb), pair2(vya, vyb), pair2(vza, vzb)};
     const f2 d2 = dot2(r, r);                       // dot(rij, rij)
     f2 len;                                         // length(rij)
     if (INRANGE) {
@@ -784,7 +800,8 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                                      const R *__restrict__ sPres, V3<R> pos1, V3<R> vel1, R dens, R pres,
                                      const uint32_t *lbase, uint32_t lstride, HitCounts hc, uint32_t self = 0xffffffffu,
                                      const R *pre = nullptr, const typename Vec4T<R>::type *__restrict__ gpos = nullptr,
-                                     const typename Vec4T<R>::type *__restrict__ gvel = nullptr)
+                                     const typename Vec4T<R>::type *__restrict__ gvel = nullptr, const uint32_t *__restrict__ lroot = nullptr,
+                                     uint32_t lcol = 0u)
 {
     ForceAcc<R> A;
     A.fpres = A.fvisc = A.fsurf = A.fbound = mk3<R>(0, 0, 0);
@@ -880,19 +897,19 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         auto walk = [&](auto inRange, const InRange &IG, bool &bad) {
             ForceAcc<R> S;
             S.fpres = S.fvisc = S.fsurf = S.fbound = mk3<R>(0, 0, 0);
-            uint32_t e0 = nf > 0 ? lbase[0] : 0u, e1 = nf > 1 ? lbase[lstride] : e0;
+            // (the lists of the packed walk live in global memory: row k of the wave-uniform root + the lane's column, so that the address is a
+            // scalar base + a 32-bit lane offset and no 64-bit per-lane pointer stays live across the loop)
+            auto entry = [&](int k) { return lroot[(size_t)k * lstride + lcol]; };
+            uint32_t e0 = nf > 0 ? entry(0) : 0u, e1 = nf > 1 ? entry(1) : e0;
             for (int k = 0; k < nf; k += 2) {
 #if defined(NRS_ABL_FORCE_COALESCED) // timing ablation: the gathers of a wave hit consecutive slots (what a staged walk could reach at best)
                 const uint32_t j0 = (blockIdx.x * BLOCK + threadIdx.x + (uint32_t)k * 3u) % G.nSorted, j1 = (j0 + 1u) % G.nSorted;
-#elif defined(NRS_ABL_FORCE_QUAD) // timing ablation: the four lanes of a quad gather the hits of the quad's first owner (16 distinct owners per gather)
-                const uint32_t *lq = lbase - (threadIdx.x & 3u);
-                const uint32_t j0 = (lq[(uint32_t)k * lstride] & HIT_INDEX) % G.nSorted, j1 = (lq[(uint32_t)min(k + 1, HIT_CAP - 1) * lstride] & HIT_INDEX) % G.nSorted;
 #else
                 const uint32_t j0 = e0 & HIT_INDEX, j1 = e1 & HIT_INDEX;
 #endif
                 const bool two = k + 1 < nf;
-                const uint32_t n0 = k + 2 < nf ? lbase[(uint32_t)(k + 2) * lstride] : 0u;
-                const uint32_t n1 = k + 3 < nf ? lbase[(uint32_t)(k + 3) * lstride] : n0;
+                const uint32_t n0 = k + 2 < nf ? entry(k + 2) : 0u;
+                const uint32_t n1 = k + 3 < nf ? entry(k + 3) : n0;
 #if defined(NRS_ABL_FORCE_NOVEL) // timing ablation: one gather per hit
                 const float4 pa = gpos[j0], pb = gpos[j1], va = pa, vb = pb;
 #else
@@ -1288,7 +1305,7 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
         else // (the context hands out lists only together with the pairs array of the same density launch)
             A = forces_from_hits<R, KSET, SURF, HAS_B, false, NRS_FORCE_PAIRS != 0, (HAS_B && KSET == KS_MONAGHAN)>(P, G, sPos, sVel, sDens, sPres, pos1, vel1, dens, pres, hb.hits + i, hb.stride,
                                                                                      hc, 0xffffffffu, nullptr, reinterpret_cast<const typename Vec4T<R>::type *>(hb.gpos),
-                                                                                     reinterpret_cast<const typename Vec4T<R>::type *>(hb.gvel));
+                                                                                     reinterpret_cast<const typename Vec4T<R>::type *>(hb.gvel), hb.hits, i);
         f = sesph_total_force<R>(P, A, dens);
     }
     forces_epilogue<R, KSET, SURF, HAS_B, FUSE>(P, p4, v4, f, forces, fo, i);
@@ -1298,7 +1315,7 @@ NRS_DEV void forces_lists_particle(const Params<R> &P, const GridView<R> &G, con
 // false for the interior code
 // (the packed two-hit walk of the interior code needs 94 VGPRs: 5 waves per SIMD; the scalar walk is bounded for 7)
 template <typename R, int KSET, bool SURF, bool HAS_B, bool FUSE, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? ((NRS_PACKED_HITS && NRS_FORCE_PAIRS && KSET == KS_MULLER && !HAS_B) ? FORCES_PACKED_MIN_WAVES : FORCES_LISTS_MIN_WAVES) : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? ((NRS_PACKED_HITS && NRS_FORCE_PAIRS && KSET == KS_MULLER && !HAS_B) ? (FUSE ? FORCES_PACKED_MIN_WAVES : FORCES_PACKED_MIN_WAVES_UNFUSED) : FORCES_LISTS_MIN_WAVES) : 1)) void k_forces_lists(Params<R> P, GridView<R> G, HitBuffer hb,
                                                         const typename Vec4T<R>::type *__restrict__ sPos,
                                                         const typename Vec4T<R>::type *__restrict__ sVel,
                                                         const R *__restrict__ sDens, const R *__restrict__ sPres,

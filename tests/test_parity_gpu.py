@@ -546,12 +546,20 @@ def test_in_range_division_guards(hip_lib):
     c[1200:1300, :3] = c[200:300, :3]
     cases.append(("close and coincident pairs", c))
     cases.append(("next to the grid origin", cloud([-1.1 + 3.0 * h, 0.1, -0.2], 3000, 2.9)))
-    for name, pos in cases:
+    zero_origin = base.copy()
+    zero_origin["worldOrigin"][0] = (0.0, -1.1, -1.1)      # (then x - origin can be tiny: the density walk decides by a vote of the owners)
+    cases.append(("grid origin at zero", cloud([3.0 * h, 0.1, -0.2], 3000, 2.9), zero_origin))
+    tiny_origin = cloud([3.0 * h, 0.1, -0.2], 3000, 2.9)
+    tiny_origin[0:60, 0] = np.repeat(np.float32([1e-30, 3e-29, -2e-31, 1e-40, 5e-28, 0.0]), 10)
+    cases.append(("grid origin at zero, tiny x", tiny_origin, zero_origin))
+    for case in cases:
+        name, pos = case[:2]
+        base_case = case[2] if len(case) > 2 else base
         vel = np.zeros_like(pos)
         vel[:, :3] = rng.uniform(-0.5, 0.5, (len(pos), 3)).astype(np.float32)
         outs = []
         for ref in (False, True):
-            s = capi.Solver(base, len(pos), reference_order=ref)
+            s = capi.Solver(base_case, len(pos), reference_order=ref)
             s.set_particles(pos, vel)
             s.set_boundaries(None, None, update_grid=True)
             s.step_partial(capi.STAGE_FORCES)
@@ -562,7 +570,7 @@ def test_in_range_division_guards(hip_lib):
             s.close()
         for a, b in zip(*outs):
             np.testing.assert_array_equal(a, b, err_msg=name)    # (NaN == NaN here)
-        o = Oracle(base, False, 1, SESPH)
+        o = Oracle(base_case, False, 1, SESPH)
         o.set_particles(pos, vel)
         o.set_boundaries(None, None, update_grid=True)
         o.step(1, stop=STOP_FORCES)
