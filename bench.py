@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured-achievable)
-TRAFFIC_PROFILE = "r03_ns10M_flowing_hbm_traffic.json"  # committed rocprofv3 PMC summary (of the same window) the `traffic` field is read from
+TRAFFIC_PROFILE = "r03b_ns10M_flowing_hbm_traffic.json"  # committed rocprofv3 PMC summary (of the same window) the `traffic` field is read from
 DEFAULT_SPIN_UP, DEFAULT_DT = 3000, 2.5e-4
 
 

@@ -346,7 +346,10 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
             NRSCHK(hitBuf.alloc((size_t)HIT_CAP * cap * 4));
             NRSCHK(hitCounts.alloc((size_t)cap * 4));
             if (NRS_COMPACT_SCAN) NRSCHK(qpos.alloc(((size_t)cap + 4) * QP_BYTES));
-            if (NRS_FORCE_PAIRS && !iisph()) { NRSCHK(gatherPos.alloc((size_t)cap * sizeof(T4))); NRSCHK(gatherVel.alloc((size_t)cap * sizeof(T4))); }
+            if (NRS_FORCE_PAIRS && !iisph()) {
+                if (NRS_GATHER_INTERLEAVED) NRSCHK(gatherPos.alloc((size_t)cap * 2 * sizeof(T4)));
+                else { NRSCHK(gatherPos.alloc((size_t)cap * sizeof(T4))); NRSCHK(gatherVel.alloc((size_t)cap * sizeof(T4))); }
+            }
             if ((cfg.flags & NRS_FLAG_FAST_ARITH) && !iisph() && std::is_same<R, float>::value && KSET == KS_MULLER)
                 NRSCHK(fastQ.alloc((size_t)cap * sizeof(FastPair)));
         }
@@ -813,12 +816,16 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         if (slabOn) { G.actLo = slab.lo - 1; G.actHi = slab.hi + 1; } // density is also needed one cell beyond the cuts
         // the density kernel's hit lists are handed to the force kernel when both run in this call
         HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
-        if (NRS_FORCE_PAIRS) { hb.gpos = gatherPos.p; hb.gvel = gatherVel.p; hb.svel = velB.p; }
+        if (NRS_FORCE_PAIRS) { hb.gpos = gatherPos.p; hb.gvel = NRS_GATHER_INTERLEAVED ? (void *)(gatherPos.as<T4>() + 1) : gatherVel.p; hb.svel = velB.p; }
         if constexpr (std::is_same<R, float>::value) { if (fastArith() && fastQ.p && !stagedScan()) hb.fast = fastQ.as<FastPair>(); }
         const bool share = !refOrder() && lists_ok() && stop != NRS_STAGE_DENSITY;
-        NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         const bool fast = fastArith() && share && fastQ.p;
-        if (HAS_B && share && wallListed && !refOrder()) NRSCHK(build_wall_list(N));
+        if (HAS_B && share && wallListed && !refOrder()) { // (timed with the reorder stage, whose tile counts it finishes: the density stage is its one launch)
+            NRSCHK(ev_begin(NRS_STAGE_REORDER, true));
+            NRSCHK(build_wall_list(N));
+            NRSCHK(ev_end());
+        }
+        NRSCHK(ev_begin(NRS_STAGE_DENSITY));
         const WallList wv = wall_view();
         bool didStaged = false;
         if constexpr (std::is_same<R, float>::value) {
@@ -958,10 +965,14 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         // one neighbourhood scan per step: its hit lists drive the rest of the chain (nrs_kernels_iisph.h)
         const bool lists = iisph_lists();
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
-        NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
         // (wall workgroups for the scan only: the list kernels of the chain treat every particle alike)
         const bool walls = HAS_B && lists && wallListed;
-        if (walls) NRSCHK(build_wall_list(N));
+        if (walls) {
+            NRSCHK(ev_begin(NRS_STAGE_REORDER, true));
+            NRSCHK(build_wall_list(N));
+            NRSCHK(ev_end());
+        }
+        NRSCHK(ev_begin(NRS_STAGE_I_DENSITY));
         const WallList wv = wall_view();
         if (lists) launch_density_wide<R, KSET, HAS_B>(stream, P, G, hb, posB.as<T4>(), dens.as<R>(), N, walls ? &wv : (const WallList *)nullptr);
         else hipLaunchKernelGGL((k_density_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, posB.as<T4>(), dens.as<R>(), (R *)nullptr, N);

@@ -104,6 +104,11 @@ constexpr int SCAN_BATCH = 4; // candidate positions fetched per thread per memo
 // lst[HIT_CAP-1 .. HIT_CAP-nb] (descending slots, ascending visiting order); both lists are ordered by cell
 // number, so the process phase restores the reference's order (cell by cell: fluid, then boundary) by merging.
 struct HitCounts { int nf, nb; bool over; bool anyB; }; // anyB: some of the 27 cells holds boundary particles
+// NRS_GATHER_INTERLEAVED (the gather records of HitBuffer): the two records of a slot side by side (slot j at 32 j bytes: both loads of a hit fall into one 128-byte line)
+#ifndef NRS_GATHER_INTERLEAVED
+#define NRS_GATHER_INTERLEAVED 1
+#endif
+constexpr uint32_t GATHER_STRIDE = NRS_GATHER_INTERLEAVED ? 2u : 1u;
 template <typename R> struct PrePair { R prq, mrho; }; // (p / rho^2, m / rho) of one sorted slot, see HitBuffer::pairs
 
 template <typename R> struct Sweep {
@@ -630,11 +635,7 @@ NRS_DEV BoundaryTerms<R, KSET> boundary_terms(const Params<R> &P, V3<R> pos1, V3
 #ifndef NRS_PACKED_HITS
 #define NRS_PACKED_HITS 1
 #endif
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct V3x2 { f2 x, y, z; };
-NRS_DEV f2 splat2(float v) { f2 r = {v, v}; return r; }
-NRS_DEV f2 pair2(float a, float b) { f2 r = {a, b}; return r; }
-NRS_DEV f2 dot2(const V3x2 &a, const V3x2 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // ((x + y) + z), as dot()
+// (f2, V3x2, splat2, pair2, dot2 and the packed forms of the in-range steps: nrs_math.h)
 // Two IEEE divisions a.x / b.x, a.y / b.y.  The compiler expands a correctly rounded fp32 division into v_div_scale (x2), v_rcp, five
 // fused multiply-adds and a multiply, v_div_fmas, v_div_fixup (AMDGPU LowerFDIV32); here the six arithmetic steps of the two
 // divisions run as v_pk_fma_f32 / v_pk_mul_f32 on both at once — the same operations on the same operands, 16 instructions instead
@@ -681,31 +682,6 @@ NRS_DEV f2 div2(f2 a, f2 b)
 // Measured (tools/ab_flowing.sh, tools/busy_flowing.sh): vector instructions per wave of the force launch 2280 -> 1710 in the bench's window
 // and VALU busy 81 % -> 60 % — and the launch takes the same 0.88 ms there, because in that window it is bound by the L1 (0.57 line
 // accesses per cycle and CU, TA 71-77 % busy: 34 distinct lines per gather instruction); at rest, six hits per particle, 0.382 -> 0.351 ms.
-NRS_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-NRS_DEV f2 rcp_refined2(f2 d) // steps 1-3: the reciprocal every quotient by d is built from
-{
-    const f2 r = pair2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
-    return fma2(fma2(-d, r, splat2(1.0f)), r, r);
-}
-NRS_DEV f2 div_steps2(f2 n, f2 d, f2 y) // steps 4-8
-{
-    const f2 nd = -d;
-    const f2 q0 = n * y;
-    const f2 q1 = fma2(fma2(nd, q0, n), y, q0);
-    return fma2(fma2(nd, q1, n), y, q1);
-}
-NRS_DEV f2 sqrt_inrange2(f2 x)
-{
-    const float sa = __builtin_amdgcn_sqrtf(x.x), sb = __builtin_amdgcn_sqrtf(x.y);
-    const f2 s = pair2(sa, sb);
-    const f2 dn = pair2(__uint_as_float(__float_as_uint(sa) - 1u), __uint_as_float(__float_as_uint(sb) - 1u));
-    const f2 up = pair2(__uint_as_float(__float_as_uint(sa) + 1u), __uint_as_float(__float_as_uint(sb) + 1u));
-    const f2 vp = fma2(-dn, s, x), vs = fma2(-up, s, x);
-    f2 o = s;
-    o.x = 0.f >= vp.x ? dn.x : o.x; o.x = 0.f < vs.x ? up.x : o.x;
-    o.y = 0.f >= vp.y ? dn.y : o.y; o.y = 0.f < vs.y ? up.y : o.y;
-    return o;
-}
 struct InRange { float yVisc; uint32_t loBits, spanBits; bool constantsOk; };
 NRS_DEV InRange in_range_setup(const Params<float> &P)
 {
@@ -825,7 +801,7 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
         V3<R> rij, vij;
         R pOverRhoSqNb, mOverRhoNb; // pNb / (rhoNb * rhoNb), m2 / rhoNb
         if (PAIRS) { // the neighbour's two gather records (HitBuffer)
-            const typename Vec4T<R>::type a = gpos[j], b = gvel[j];
+            const typename Vec4T<R>::type a = gpos[GATHER_STRIDE * j], b = gvel[GATHER_STRIDE * j];
             rij = pos1 - xyz<R>(a);
             if (STRICT && ((j == self) || !(length(rij) < ir))) return; // the loop's own tests (:494,:505)
             vij = vel1 - xyz<R>(b);
@@ -911,9 +887,9 @@ NRS_DEV ForceAcc<R> forces_from_hits(const Params<R> &P, const GridView<R> &G,
                 const uint32_t n0 = k + 2 < nf ? entry(k + 2) : 0u;
                 const uint32_t n1 = k + 3 < nf ? entry(k + 3) : n0;
 #if defined(NRS_ABL_FORCE_NOVEL) // timing ablation: one gather per hit
-                const float4 pa = gpos[j0], pb = gpos[j1], va = pa, vb = pb;
+                const float4 pa = gpos[GATHER_STRIDE * j0], pb = gpos[GATHER_STRIDE * j1], va = pa, vb = pb;
 #else
-                const float4 pa = gpos[j0], pb = gpos[j1], va = gvel[j0], vb = gvel[j1];
+                const float4 pa = gpos[GATHER_STRIDE * j0], pb = gpos[GATHER_STRIDE * j1], va = gvel[GATHER_STRIDE * j0], vb = gvel[GATHER_STRIDE * j1];
 #endif
                 const PairTerms2 T = fluid_terms2_muller<SURF, decltype(inRange)::value>(P, pos1, vel1, own, c0, wAtDiameter, diameter2, pa, pb, va, vb,
                                                                                         PrePair<float>{pa.w, va.w}, PrePair<float>{pb.w, vb.w}, IG, bad);
@@ -1005,8 +981,8 @@ template <typename R>
 NRS_DEV void publish_gather_records(const Params<R> &P, const HitBuffer &hb, uint32_t i, V3<R> p, typename Vec4T<R>::type v, R d, R pr)
 {
     typedef typename Vec4T<R>::type T4;
-    reinterpret_cast<T4 *>(hb.gpos)[i] = mk4<R>(p, pr / (d * d));
-    reinterpret_cast<T4 *>(hb.gvel)[i] = mk4<R>(xyz<R>(v), P.particleMass / d);
+    reinterpret_cast<T4 *>(hb.gpos)[GATHER_STRIDE * i] = mk4<R>(p, pr / (d * d));
+    reinterpret_cast<T4 *>(hb.gvel)[GATHER_STRIDE * i] = mk4<R>(xyz<R>(v), P.particleMass / d);
 }
 NRS_DEV uint32_t pack_counts(HitCounts hc)
 {

@@ -81,6 +81,39 @@ NRS_DEV float sqrt_inrange(float x) // 2^-96 <= x < inf
     return o;
 }
 
+// two floats per lane on packed fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 round each component like the scalar forms): the pairs of
+// the force walk (two hits) and of the density walk (two list entries), and the in-range steps above for both components at once
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V3x2 { f2 x, y, z; };
+NRS_DEV f2 splat2(float v) { f2 r = {v, v}; return r; }
+NRS_DEV f2 pair2(float a, float b) { f2 r = {a, b}; return r; }
+NRS_DEV f2 dot2(const V3x2 &a, const V3x2 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // ((x + y) + z), as dot()
+NRS_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+NRS_DEV f2 rcp_refined2(f2 d) // steps 1-3: the reciprocal every quotient by d is built from
+{
+    const f2 r = pair2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+    return fma2(fma2(-d, r, splat2(1.0f)), r, r);
+}
+NRS_DEV f2 div_steps2(f2 n, f2 d, f2 y) // steps 4-8
+{
+    const f2 nd = -d;
+    const f2 q0 = n * y;
+    const f2 q1 = fma2(fma2(nd, q0, n), y, q0);
+    return fma2(fma2(nd, q1, n), y, q1);
+}
+NRS_DEV f2 sqrt_inrange2(f2 x)
+{
+    const float sa = __builtin_amdgcn_sqrtf(x.x), sb = __builtin_amdgcn_sqrtf(x.y);
+    const f2 s = pair2(sa, sb);
+    const f2 dn = pair2(__uint_as_float(__float_as_uint(sa) - 1u), __uint_as_float(__float_as_uint(sb) - 1u));
+    const f2 up = pair2(__uint_as_float(__float_as_uint(sa) + 1u), __uint_as_float(__float_as_uint(sb) + 1u));
+    const f2 vp = fma2(-dn, s, x), vs = fma2(-up, s, x);
+    f2 o = s;
+    o.x = 0.f >= vp.x ? dn.x : o.x; o.x = 0.f < vs.x ? up.x : o.x;
+    o.y = 0.f >= vp.y ? dn.y : o.y; o.y = 0.f < vs.y ? up.y : o.y;
+    return o;
+}
+
 // x^3 the way g++ evaluates pow(SReal,int): in double, rounded once to SReal (kernels_impl.cuh:95)
 template <typename R> NRS_DEV R cube_via_double(R x) { double d = (double)x; return (R)(d * d * d); }
 // powf(x,2) (kernels_impl.cuh:113): float square, also in fp64 builds

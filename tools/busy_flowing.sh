@@ -1,16 +1,19 @@
 #!/bin/bash
 # Busy / memory counters of the density and force launches ON THE BENCH'S OWN STATE (NS scene, 10 M particles, after 3000 steps at
-# dt = 2.5e-4 s) for the in-tree library and the tools/_bin variants named on the command line: two rocprofv3 --pmc passes each over
-# `density_ablate2.py time <state>` (5 evaluations of the density + force stages).  Writes gpurun_out/busyflow/busy.json (raw per-dispatch
+# dt = 2.5e-4 s) for the in-tree library and the tools/_bin variants named on the command line: two rocprofv3 --pmc passes each.
+# BUSY_MODE=partial (the first version of this tool): over `density_ablate2.py time <state>`, 5 evaluations of the density + force stages of
+# a PARTIAL step (the unfused force launch); default: over the bench's own command, full (fused) steps, the last 5 dispatches of each kernel.  Writes gpurun_out/busyflow/busy.json (raw per-dispatch
 # averages and derived fractions, the per-XCD correction as in tools/busy_counters.sh); raw profiler output stays in /tmp on the box.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=/tmp/busyflow; mkdir -p $OUT $R/gpurun_out/busyflow
-[ -f /tmp/flow3000.npz ] || NEREUS_ABL_DT=2.5e-4 timeout -k 10 300 python3 $R/tools/density_ablate2.py save 3000 /tmp/flow3000.npz > $OUT/save.log 2>&1 || { tail -5 $OUT/save.log; exit 1; }
+CMD="$R/bench.py --steps 5 --warmup 20 --resting-steps 0 --no-cpu-baseline"
+if [ "$BUSY_MODE" = partial ]; then CMD="$R/tools/density_ablate2.py time /tmp/flow3000.npz"; fi
+[ "$BUSY_MODE" != partial ] || [ -f /tmp/flow3000.npz ] || NEREUS_ABL_DT=2.5e-4 timeout -k 10 300 python3 $R/tools/density_ablate2.py save 3000 /tmp/flow3000.npz > $OUT/save.log 2>&1 || { tail -5 $OUT/save.log; exit 1; }
 for v in main "$@"; do
   if [ $v = main ]; then unset NEREUS_HIP_LIB; else export NEREUS_HIP_LIB=$R/tools/_bin/libnereus_hip_$v.so; fi
-  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES TA_BUSY_avr SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY -d $OUT/${v}_a -o p --output-format csv -- python3 $R/tools/density_ablate2.py time /tmp/flow3000.npz > $OUT/${v}_a.log 2>&1 || { tail -5 $OUT/${v}_a.log; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/${v}_b -o p --output-format csv -- python3 $R/tools/density_ablate2.py time /tmp/flow3000.npz > $OUT/${v}_b.log 2>&1 || { tail -5 $OUT/${v}_b.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES TA_BUSY_avr SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY -d $OUT/${v}_a -o p --output-format csv -- python3 $CMD > $OUT/${v}_a.log 2>&1 || { tail -5 $OUT/${v}_a.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/${v}_b -o p --output-format csv -- python3 $CMD > $OUT/${v}_b.log 2>&1 || { tail -5 $OUT/${v}_b.log; exit 1; }
 done
 python3 - "$OUT" main "$@" <<'PY'
 import csv,sys,glob,collections,json,os
@@ -26,6 +29,8 @@ for v in sys.argv[2:]:
             k=r["Kernel_Name"]
             nm="density" if "k_density_tiled" in k else ("forces" if "k_forces_lists" in k else None)
             if nm: acc[nm][r["Counter_Name"]+("" if p=="a" or r["Counter_Name"]!="GRBM_GUI_ACTIVE" else "_b")].append(float(r["Counter_Value"]))
+    for nm in acc:
+        for k in acc[nm]: acc[nm][k]=acc[nm][k][-5:]   # the last five dispatches: the timed window of the bench's command
     doc["variants"][v]={}
     for nm,c in acc.items():
         m={k:sum(x)/len(x) for k,x in c.items()}
