@@ -1085,7 +1085,7 @@ NRS_DEV void density_tiled_particle(const Params<R> &P, const GridView<R> &G, co
 #else
         hc = Sweep<R>::template scan_compact<BLOCK>(P, G, p, lst);
 #endif
-#if defined(NRS_ABL_NOPROCESS)
+#if defined(NRS_ABL_NOPROCESS) || defined(NRS_ABL_NOAPPEND) // (NOAPPEND: the scan left its entries unwritten — nobody may read them)
         d = (R)hc.nf;
         hc.nf = 0; hc.over = false; // (publish empty lists: the entries carry row tags only)
 #else
