@@ -1302,6 +1302,9 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? ((NRS_PACKED_HITS && NRS_F
     uint32_t block = blockIdx.x, blocks = gridDim.x;
     if (DEFER) {
         if (block < wallBlocks) {
+#if defined(NRS_ABL_NOWALL_F) // timing ablation: the wall particles get no force evaluation (and are not integrated)
+            return;
+#endif
             const uint32_t count = *wl.count;
             for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK) {
                 const uint32_t i = wl.list[t];
