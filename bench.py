@@ -408,8 +408,10 @@ def main():
             "kernel_launches": dom_launches,
             "algorithmic_bytes_per_launch": dom_bytes,
             # (not measured in this run) which unit the gather kernels keep busy: see the committed counter summary
-            "limiter_note": ("gather kernels are bound by vector-instruction issue and L1 address traffic, not by HBM bytes: "
-                             "profiles/r03_busy_2M.json") if dominant in ("density", "forces") else None,
+            "limiter_note": ("the two gather launches are within a few per cent of each other; the density launch (the step's only neighbour "
+                             "search; it also publishes the hit lists and the gather records) is bound by vector-instruction issue, the "
+                             "fused force launch by L1 line accesses and their misses, neither by HBM bytes: "
+                             "profiles/r03_busy_flowing_10M.json") if dominant in ("density", "forces") else None,
             "whole_step": {
                 "bytes_per_particle_step": bpp,
                 "radix_passes": passes,
