@@ -10,7 +10,10 @@ import shutil
 import sys
 from collections import defaultdict
 
-SHORT = [("k_density_staged", "k_density_staged"), ("k_forces_fast", "k_forces_fast"), ("k_wall_count", "k_wall_count"),
+SHORT = [("k_displacement_lists", "k_displacement_lists"), ("k_advection_lists", "k_advection_lists"), ("k_sumdij_lists", "k_sumdij_lists"),
+         ("k_pressure_lists", "k_pressure_lists"), ("k_pforce_lists", "k_pforce_lists"), ("k_iisph_integrate", "k_iisph_integrate"),
+         ("k_sum_partial", "k_sum_partial"), ("k_sum_final", "k_sum_final"),
+         ("k_density_staged", "k_density_staged"), ("k_forces_fast", "k_forces_fast"), ("k_wall_count", "k_wall_count"),
          ("k_wall_compact", "k_wall_compact"), ("k_density_tiled", "k_density_tiled"), ("k_forces_lists", "k_forces_lists"), ("k_forces_tiled", "k_forces_tiled"),
          ("k_reorder_merged", "k_reorder_merged"), ("k_reorder_boundary", "k_reorder_boundary"), ("k_reorder", "k_reorder"),
          ("k_clear_cells", "k_clear_cells"), ("k_hash", "k_hash"), ("k_resort_split", "k_resort_split"),
@@ -40,10 +43,10 @@ def per_kernel(path, counter, last=0):
 
 
 def tail_stats(trace_csv, dst_csv, steps):
-    """per-kernel launch statistics over the LAST `steps` steps of a kernel trace (a step = one k_forces_* launch)"""
+    """per-kernel launch statistics over the LAST `steps` steps of a kernel trace (a step = one k_forces_* / k_iisph_integrate launch)"""
     rows = list(csv.DictReader(open(trace_csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "k_forces_" in r["Kernel_Name"]]
+    marks = [int(r["Start_Timestamp"]) for r in rows if "k_forces_" in r["Kernel_Name"] or "k_iisph_integrate" in r["Kernel_Name"]]
     t0 = marks[-steps] if len(marks) >= steps else marks[0]
     first_stage = min((int(r["Start_Timestamp"]) for r in rows if int(r["Start_Timestamp"]) >= t0), default=t0)
     acc = defaultdict(list)
