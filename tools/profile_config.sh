@@ -9,4 +9,4 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- pytho
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --no-cpu-baseline "$@" --steps 5 > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --no-cpu-baseline "$@" --steps 5 > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
 cd $R && NEREUS_PROFILE_OUT=$R/gpurun_out/prof_$TAG python3 tools/summarize_profile.py $OUT $NAME "$WL" $NP $KEEP > $R/gpurun_out/prof_$TAG/summary.txt 2>&1 || { tail -5 $R/gpurun_out/prof_$TAG/summary.txt; exit 1; }
-tail -3 $OUT/trace.log | cut -c1-300 > $R/gpurun_out/prof_$TAG/bench_line_under_profiler.txt
+grep "^{" $OUT/trace.log | tail -1 > $R/gpurun_out/prof_$TAG/bench_line_under_profiler.json
