@@ -30,6 +30,7 @@
 
 namespace nrs {
 
+
 // Walk the merged hit lists; f(j, isBoundary, newPartial) with newPartial = first hit of a (cell, kind) group.
 template <typename F> NRS_DEV void for_each_hit(const uint32_t *lbase, uint32_t lstride, HitCounts hc, F &&f)
 {
@@ -108,6 +109,18 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
                         db = db + rb;
                     }
                 }
+    } else if (!HAS_B || hc.nb == 0) { // no boundary hits: the fluid entries alone, batched
+        V3<R> part = mk3<R>(0, 0, 0);
+        uint32_t prevTag = 0xffffffffu;
+        walk_fluid_batched(hb.hits + i, hb.stride, hc.nf, [&](uint32_t j) { return sPos[j]; },
+                           [&](uint32_t j, uint32_t tag, const typename Vec4T<R>::type &q) {
+                               if (tag != prevTag) { df = df + part; part = mk3<R>(0, 0, 0); prevTag = tag; }
+                               if (j == i) return;
+                               const V3<R> d = pos1 - xyz<R>(q);
+                               const float rlen = length_listed(dot(d, d));
+                               if (rlen < ir) part = part - ((pm / (dens * dens)) * Wdefault_grad_len<R>(d, rlen, ir, kpg));
+                           });
+        df = df + part;
     } else {
         V3<R> part = mk3<R>(0, 0, 0);
         bool partB = false;
@@ -222,6 +235,26 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void
                         aii += rb;
                     }
                 }
+    } else if (!HAS_B || hc.nb == 0) {
+        // no boundary hits (all but the particles next to a wall): both sums in ONE batched walk of the fluid entries — the same entries in
+        // the same order feed rho_adv (one partial per cell, `length < h` as its loop tests) and a_ii (one partial per cell, no test), and
+        // W_grad of a hit is formed once for both
+        R part = (R)0.0, pa = (R)0.0;
+        uint32_t prevTag = 0xffffffffu;
+        const R dpi = (pm) / (dens * dens);
+        struct Nb { typename Vec4T<R>::type q, va; };
+        walk_fluid_batched(hb.hits + i, hb.stride, hc.nf, [&](uint32_t j) { return Nb{sPos[j], I.velAdv[j]}; },
+                           [&](uint32_t j, uint32_t tag, const Nb &nb) {
+                               if (tag != prevTag) { rho_advf += part; part = (R)0.0; aii += pa; pa = (R)0.0; prevTag = tag; }
+                               if (j == i) return;
+                               const V3<R> d = pos1 - xyz<R>(nb.q);
+                               const float rlen = length_listed(dot(d, d));
+                               const V3<R> grad = Wdefault_grad_len<R>(d, rlen, ir, kpg);
+                               if (rlen < ir) part += (dt * pm * dot(velAdv1 - xyz<R>(nb.va), grad));
+                               pa += (pm * dot((diif + diib) - dpi * grad, grad));
+                           });
+        rho_advf += part;
+        aii += pa;
     } else {
         // rho_adv: fluid partials go to rho_advf, boundary partials to rho_advb, one partial per cell
         R part = (R)0.0;
@@ -303,17 +336,15 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R>
                     dijpj = dijpj + res;
                 }
     } else {
-        hc.nb = 0; // boundary hits play no part here
+        // boundary hits play no part here: the fluid entries alone, one partial sum per cell tag (the list is in cell order)
         V3<R> part = mk3<R>(0, 0, 0);
-        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool fresh) {
-            if (fresh) { dijpj = dijpj + part; part = mk3<R>(0, 0, 0); }
-            if (j != i) {
-                const V3<R> d = pos1 - xyz<R>(sPos[j]);
-                const R p_lj = I.P_l[j];
-                const R densj = sDens[j];
-                part = part - ((pm / (densj * densj)) * p_lj * W_grad<R, KSET>(d, ir, kpg));
-            }
-        });
+        uint32_t prevTag = 0xffffffffu;
+        struct Nb { typename Vec4T<R>::type q; R pl, dn; };
+        walk_fluid_batched(hb.hits + i, hb.stride, hc.nf, [&](uint32_t j) { return Nb{sPos[j], I.P_l[j], sDens[j]}; },
+                           [&](uint32_t j, uint32_t tag, const Nb &nb) {
+                               if (tag != prevTag) { dijpj = dijpj + part; part = mk3<R>(0, 0, 0); prevTag = tag; }
+                               if (j != i) part = part - ((pm / (nb.dn * nb.dn)) * nb.pl * W_grad_listed<R, KSET>(pos1 - xyz<R>(nb.q), ir, kpg));
+                           });
         dijpj = dijpj + part;
     }
     I.sumDij[i] = mk4<R>(dijpj, (R)0.0);
@@ -385,8 +416,14 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
                     }
                 }
     } else {
-        hc.nb = 0;
-        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
+        struct Nb { typename Vec4T<R>::type q, dii, sdj; R pl; };
+        walk_fluid_batched(hb.hits + i, hb.stride, hc.nf, [&](uint32_t j) { return Nb{sPos[j], I.diiSum[j], I.sumDij[j], I.P_l[j]}; },
+                           [&](uint32_t j, uint32_t, const Nb &nb) {
+                               if (j == skip) return;
+                               const V3<R> grad = W_grad_listed<R, KSET>(pos1 - xyz<R>(nb.q), ir, kpg);
+                               const V3<R> d_ji_pi = (dpi * (grad)) * nb.pl;
+                               fsum += pm * dot(dijpj - xyz<R>(nb.dii) * nb.pl - (xyz<R>(nb.sdj) - d_ji_pi), grad);
+                           });
     }
     const R omega = (R)0.5;
     R rho_corr = rho_adv + fsum + bsum;
@@ -431,8 +468,13 @@ __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R>
         fp = fp + contrib;
     };
     if ((!HAS_B || !hc.anyB) && !hc.over) { // no boundary particles in any of the 27 cells: only the fluid list contributes
-        hc.nb = 0;
-        for_each_hit(hb.hits + i, hb.stride, hc, [&](uint32_t j, bool, bool) { if (j != skip) term(j); });
+        struct Nb { typename Vec4T<R>::type q; R pj, dn; };
+        walk_fluid_batched(hb.hits + i, hb.stride, hc.nf, [&](uint32_t j) { return Nb{sPos[j], sPres[j], sDens[j]}; },
+                           [&](uint32_t j, uint32_t, const Nb &nb) {
+                               if (j == skip) return;
+                               const V3<R> grad = W_grad_listed<R, KSET>(pos1 - xyz<R>(nb.q), ir, kpg);
+                               fp = fp + (-pm * pm * (p / (dens * dens) + nb.pj / (nb.dn * nb.dn)) * grad);
+                           });
     } else {
         const I3 gp = calcGridPos<R>(P, pos1);
         int kf = 0; // cursor into the fluid list (ascending cell number)

@@ -208,6 +208,30 @@ template <typename R, int KSET> NRS_DEV V3<R> W_grad(V3<R> r, R ir, R kpg)
     if (KSET == KS_MULLER) return Wdefault_grad<R>(r, ir, kpg);
     return Wmonaghan_grad<R>(r, ir);
 }
+// length() and W_grad() for the hit-list walks of the IISPH chain (Muller kernels): the square root as the bare steps of the compiler's
+// expansion ("operands in range" above; an argument below 2^-96 — coincident particles — takes sqrtf).  Same values, bit for bit: dot() and
+// length() are float in both precisions, Wdefault_grad squares that float length.
+NRS_DEV float length_listed(float d2)
+{
+#if NRS_INRANGE_DIV
+    return d2 >= 0x1p-96f ? sqrt_inrange(d2) : sqrt_rn(d2);
+#else
+    return sqrt_rn(d2);
+#endif
+}
+template <typename R> NRS_DEV V3<R> Wdefault_grad_len(V3<R> r, float rlen, R h, R kpoly_grad) // Wdefault_grad with length(r) handed in
+{
+    R r2 = rlen * rlen;
+    R h2 = h * h;
+    if (r2 > h2) return mk3<R>(0, 0, 0);
+    R b = square_via_float<R>(h2 - r2);
+    return kpoly_grad * r * b;
+}
+template <typename R, int KSET> NRS_DEV V3<R> W_grad_listed(V3<R> r, R ir, R kpg)
+{
+    if constexpr (KSET == KS_MULLER) return Wdefault_grad_len<R>(r, length_listed(dot(r, r)), ir, kpg);
+    else return W_grad<R, KSET>(r, ir, kpg);
+}
 
 // SphSimParams, byte-identical to nrs_params_f32 / nrs_params_f64 (include/nereus_hip.h)
 template <typename R> struct Params {
