@@ -965,7 +965,7 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         // one neighbourhood scan per step: its hit lists drive the rest of the chain (nrs_kernels_iisph.h)
         const bool lists = iisph_lists();
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
-        // (wall workgroups for the scan only: the list kernels of the chain treat every particle alike)
+        // (wall workgroups: for the scan and, round 3, for the list kernels with boundary loops — displacement, advection, pressure, pressure force)
         const bool walls = HAS_B && lists && wallListed;
         if (walls) {
             NRSCHK(ev_begin(NRS_STAGE_REORDER, true));
@@ -979,18 +979,26 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_DENSITY) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_DISPLACEMENT));
-        if (lists)
+        const WallList noWalls = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const uint32_t wb = wall_blocks(g.x);
+        if (lists && walls) // (wall workgroups + interior workgroups without the boundary code, as the scan: k_pressure_lists)
+            hipLaunchKernelGGL((k_displacement_lists<R, KSET, SURF, HAS_B, true>), dim3(g.x + wb), b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N, wv, wb);
+        else if (lists)
             hipLaunchKernelGGL((k_displacement_lists<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
-                               dens.as<R>(), presB.as<R>(), N);
+                               dens.as<R>(), presB.as<R>(), N, noWalls, 0u);
         else
             hipLaunchKernelGGL((k_displacement_ref<R, KSET, SURF, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
                                dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());
         if (stop == NRS_STAGE_I_DISPLACEMENT) return NRS_OK;
         NRSCHK(ev_begin(NRS_STAGE_I_ADVECTION));
-        if (lists)
+        if (lists && walls)
+            hipLaunchKernelGGL((k_advection_lists<R, KSET, HAS_B, true>), dim3(g.x + wb), b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
+                               dens.as<R>(), presB.as<R>(), N, wv, wb);
+        else if (lists)
             hipLaunchKernelGGL((k_advection_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), velB.as<T4>(),
-                               dens.as<R>(), presB.as<R>(), N);
+                               dens.as<R>(), presB.as<R>(), N, noWalls, 0u);
         else
             hipLaunchKernelGGL((k_advection_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), velB.as<T4>(),
                                dens.as<R>(), presB.as<R>(), N);
@@ -1009,8 +1017,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         if (lists) hipLaunchKernelGGL((k_sumdij_lists<R, KSET>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), N);
         else hipLaunchKernelGGL((k_sumdij_ref<R, KSET>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), N);
-        if (lists)
-            hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        const bool walls = HAS_B && lists && wallListed; // (this step's wall list: built for the scan, iisph_predict)
+        const WallList wv = wall_view(), noWalls = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const uint32_t wb = wall_blocks(g.x);
+        if (lists && walls)
+            hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B, true>), dim3(g.x + wb), b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N, wv, wb);
+        else if (lists)
+            hipLaunchKernelGGL((k_pressure_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N, noWalls, 0u);
         else
             hipLaunchKernelGGL((k_pressure_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(),
                                presB.as<R>(), N);
@@ -1028,8 +1041,13 @@ template <typename R, int KSET, bool SURF> struct Ctx : CtxBase {
         const bool lists = iisph_lists();
         const HitBuffer hb = {hitBuf.as<uint32_t>(), hitCounts.as<uint32_t>(), (uint32_t)cap};
         NRSCHK(ev_begin(NRS_STAGE_I_PFORCE));
-        if (lists)
-            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
+        const bool walls = HAS_B && lists && wallListed;
+        const WallList wv = wall_view(), noWalls = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const uint32_t wb = wall_blocks(g.x);
+        if (lists && walls)
+            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B, true>), dim3(g.x + wb), b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N, wv, wb);
+        else if (lists)
+            hipLaunchKernelGGL((k_pforce_lists<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, hb, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N, noWalls, 0u);
         else
             hipLaunchKernelGGL((k_pforce_ref<R, KSET, HAS_B>), g, b, 0, stream, P, G, I, posB.as<T4>(), dens.as<R>(), presB.as<R>(), N);
         NRSCHK(ev_end());

@@ -46,14 +46,10 @@ template <typename F> NRS_DEV void for_each_hit(const uint32_t *lbase, uint32_t 
 
 // ---- computeDisplacementFactor (sph_kernel_impl.cuh:851-963) -----------------------------------------------
 template <typename R, int KSET, bool SURF, bool HAS_B>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) void k_displacement_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
-                                                              const typename Vec4T<R>::type *__restrict__ sPos,
-                                                              const typename Vec4T<R>::type *__restrict__ sVel,
-                                                              const R *__restrict__ sDens, const R *__restrict__ sPres,
-                                                              uint32_t n)
+NRS_DEV void displacement_lists_particle(const Params<R> &P, const GridView<R> &G, const IisphArrays<R> &I, const HitBuffer &hb,
+                                         const typename Vec4T<R>::type *__restrict__ sPos, const typename Vec4T<R>::type *__restrict__ sVel,
+                                         const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t i)
 {
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
     const V3<R> pos1 = xyz<R>(sPos[i]);
     const V3<R> vel1 = xyz<R>(sVel[i]);
     const R pres = (R)0.0;
@@ -147,17 +143,44 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) voi
     I.diiSum[i] = mk4<R>(df + db, (R)0.0); // the same sum computePressure forms per neighbour (sph_kernel_impl.cuh:1420)
     watch_finite<R>(I.nonFinite, df + db);
 }
+// one sorted slot per thread — or, with WALLS (see k_pressure_lists), wall workgroups over the step's wall list + interior workgroups
+// compiled without the boundary code
+#define NRS_IISPH_WALL_SPLIT(PARTICLE_CALL_B, PARTICLE_CALL_NOB, PARTICLE_CALL_ANY)                                                    \
+    uint32_t block = blockIdx.x, blocks = gridDim.x;                                                                                  \
+    if (WALLS) {                                                                                                                      \
+        if (block < wallBlocks) {                                                                                                     \
+            const uint32_t count = *wl.count;                                                                                         \
+            for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK) { const uint32_t i = wl.list[t]; PARTICLE_CALL_B; } \
+            return;                                                                                                                   \
+        }                                                                                                                             \
+        block -= wallBlocks; blocks -= wallBlocks;                                                                                    \
+    }                                                                                                                                 \
+    const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;                                                                 \
+    if (i >= n) return;                                                                                                               \
+    if (WALLS) {                                                                                                                      \
+        if (hb.counts[i] & COUNTS_DEFERRED) return;                                                                                   \
+        PARTICLE_CALL_NOB;                                                                                                            \
+    } else {                                                                                                                          \
+        PARTICLE_CALL_ANY;                                                                                                            \
+    }
+template <typename R, int KSET, bool SURF, bool HAS_B, bool WALLS = false>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_DISP_WAVES : 1)) void k_displacement_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                              const typename Vec4T<R>::type *__restrict__ sPos,
+                                                              const typename Vec4T<R>::type *__restrict__ sVel,
+                                                              const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                              uint32_t n, WallList wl, uint32_t wallBlocks)
+{
+    NRS_IISPH_WALL_SPLIT((displacement_lists_particle<R, KSET, SURF, true>(P, G, I, hb, sPos, sVel, sDens, sPres, i)),
+                         (displacement_lists_particle<R, KSET, SURF, false>(P, G, I, hb, sPos, sVel, sDens, sPres, i)),
+                         (displacement_lists_particle<R, KSET, SURF, HAS_B>(P, G, I, hb, sPos, sVel, sDens, sPres, i)))
+}
 
 // ---- computeAdvectionFactor (sph_kernel_impl.cuh:1114-1218) --------------------------------------------------
 template <typename R, int KSET, bool HAS_B>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void k_advection_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
-                                                           const typename Vec4T<R>::type *__restrict__ sPos,
-                                                           const typename Vec4T<R>::type *__restrict__ sVel,
-                                                           const R *__restrict__ sDens, const R *__restrict__ sPres,
-                                                           uint32_t n)
+NRS_DEV void advection_lists_particle(const Params<R> &P, const GridView<R> &G, const IisphArrays<R> &I, const HitBuffer &hb,
+                                      const typename Vec4T<R>::type *__restrict__ sPos, const typename Vec4T<R>::type *__restrict__ sVel,
+                                      const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t i)
 {
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
     const V3<R> pos1 = xyz<R>(sPos[i]);
     const V3<R> vel1 = xyz<R>(sVel[i]);
     const V3<R> velAdv1 = xyz<R>(I.velAdv[i]);
@@ -303,6 +326,17 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void
     I.P_l[i] = (R)(0.5 * sPres[i]);
     I.aii[i] = aii;
 }
+template <typename R, int KSET, bool HAS_B, bool WALLS = false>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_ADV_WAVES : 1)) void k_advection_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                           const typename Vec4T<R>::type *__restrict__ sPos,
+                                                           const typename Vec4T<R>::type *__restrict__ sVel,
+                                                           const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                                           uint32_t n, WallList wl, uint32_t wallBlocks)
+{
+    NRS_IISPH_WALL_SPLIT((advection_lists_particle<R, KSET, true>(P, G, I, hb, sPos, sVel, sDens, sPres, i)),
+                         (advection_lists_particle<R, KSET, false>(P, G, I, hb, sPos, sVel, sDens, sPres, i)),
+                         (advection_lists_particle<R, KSET, HAS_B>(P, G, I, hb, sPos, sVel, sDens, sPres, i)))
+}
 
 // ---- computeSumDijPj (sph_kernel_impl.cuh:1259-1325): fluid neighbours only -----------------------------------
 template <typename R, int KSET>
@@ -354,12 +388,10 @@ __global__ __launch_bounds__(BLOCK) void k_sumdij_lists(Params<R> P, GridView<R>
 // ---- computePressure without boundary particles (sph_kernel_impl.cuh:1330-1492; Q5: skips j == inv[i], keeps self;
 //      Q7: reads P_l, writes P_l_next) ----------------------------------------------------------------------------
 template <typename R, int KSET, bool HAS_B>
-__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
-                                                          const typename Vec4T<R>::type *__restrict__ sPos,
-                                                          const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n)
+NRS_DEV void pressure_lists_particle(const Params<R> &P, const GridView<R> &G, const IisphArrays<R> &I, const HitBuffer &hb,
+                                     const typename Vec4T<R>::type *__restrict__ sPos, const R *__restrict__ sDens, R *__restrict__ sPres,
+                                     uint32_t i)
 {
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
     const uint32_t skip = I.inv[i];
     const V3<R> pos1 = xyz<R>(sPos[i]);
     const R dens = sDens[i];
@@ -442,16 +474,43 @@ __global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) voi
     sPres[i] = p_l;
     I.densCorr[i] = rho_corr;
 }
+// WALLS (the step's wall list exists: the scan of this step ran with wall workgroups, k_density_tiled): the first `wallBlocks` workgroups
+// walk the wall list with the boundary code — every lane a particle with boundary cells in its neighbourhood —, the others take one sorted
+// slot each, skip the slots flagged COUNTS_DEFERRED and are compiled WITHOUT the boundary loops (whose Q6 bounds make a lane with boundary
+// cells run 27 cell walks while the other 63 lanes of its wave wait).  Every particle is evaluated once, by the same operations.
+template <typename R, int KSET, bool HAS_B, bool WALLS = false>
+__global__ __launch_bounds__(BLOCK, (sizeof(R) == 4 ? IISPH_PRES_WAVES : 1)) void k_pressure_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                          const typename Vec4T<R>::type *__restrict__ sPos,
+                                                          const R *__restrict__ sDens, R *__restrict__ sPres, uint32_t n,
+                                                          WallList wl, uint32_t wallBlocks)
+{
+    uint32_t block = blockIdx.x, blocks = gridDim.x;
+    if (WALLS) {
+        if (block < wallBlocks) {
+            const uint32_t count = *wl.count;
+            for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK)
+                pressure_lists_particle<R, KSET, true>(P, G, I, hb, sPos, sDens, sPres, wl.list[t]);
+            return;
+        }
+        block -= wallBlocks; blocks -= wallBlocks;
+    }
+    const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (WALLS) {
+        if (hb.counts[i] & COUNTS_DEFERRED) return;
+        pressure_lists_particle<R, KSET, false>(P, G, I, hb, sPos, sDens, sPres, i);
+    } else {
+        pressure_lists_particle<R, KSET, HAS_B>(P, G, I, hb, sPos, sDens, sPres, i);
+    }
+}
 
 // ---- computePressureForce (sph_kernel_impl.cuh:1497-1620, same Q5/Q6).  One accumulator takes the fluid terms of a
 //      cell and then that cell's boundary terms, so with boundary particles the list is consumed cell by cell ------
 template <typename R, int KSET, bool HAS_B>
-__global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
-                                                        const typename Vec4T<R>::type *__restrict__ sPos,
-                                                        const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t n)
+NRS_DEV void pforce_lists_particle(const Params<R> &P, const GridView<R> &G, const IisphArrays<R> &I, const HitBuffer &hb,
+                                   const typename Vec4T<R>::type *__restrict__ sPos, const R *__restrict__ sDens, const R *__restrict__ sPres,
+                                   uint32_t i)
 {
-    const uint32_t i = xcd_tile(blockIdx.x, gridDim.x) * BLOCK + threadIdx.x;
-    if (i >= n) return;
     const uint32_t skip = I.inv[i];
     const V3<R> pos1 = xyz<R>(sPos[i]);
     const R p = sPres[i];
@@ -510,6 +569,32 @@ __global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R>
         }
     }
     I.forcesP[i] = mk4<R>(fp, (R)0.0);
+}
+// WALLS: as k_pressure_lists
+template <typename R, int KSET, bool HAS_B, bool WALLS = false>
+__global__ __launch_bounds__(BLOCK) void k_pforce_lists(Params<R> P, GridView<R> G, IisphArrays<R> I, HitBuffer hb,
+                                                        const typename Vec4T<R>::type *__restrict__ sPos,
+                                                        const R *__restrict__ sDens, const R *__restrict__ sPres, uint32_t n,
+                                                        WallList wl, uint32_t wallBlocks)
+{
+    uint32_t block = blockIdx.x, blocks = gridDim.x;
+    if (WALLS) {
+        if (block < wallBlocks) {
+            const uint32_t count = *wl.count;
+            for (uint32_t t = block * BLOCK + threadIdx.x; t < count; t += wallBlocks * BLOCK)
+                pforce_lists_particle<R, KSET, true>(P, G, I, hb, sPos, sDens, sPres, wl.list[t]);
+            return;
+        }
+        block -= wallBlocks; blocks -= wallBlocks;
+    }
+    const uint32_t i = xcd_tile(block, blocks) * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (WALLS) {
+        if (hb.counts[i] & COUNTS_DEFERRED) return;
+        pforce_lists_particle<R, KSET, false>(P, G, I, hb, sPos, sDens, sPres, i);
+    } else {
+        pforce_lists_particle<R, KSET, HAS_B>(P, G, I, hb, sPos, sDens, sPres, i);
+    }
 }
 
 } // namespace nrs
